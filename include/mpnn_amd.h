@@ -1,0 +1,183 @@
+/*
+ * mpnn_amd.h — C ABI of the MI355X (gfx950) message-passing engine.
+ *
+ * The reference (KutayTasci/MPNN) has no FFI of its own: its hot path is the
+ * Python call  MessagePassing.propagate(edge_index, x=..., edge_attr=...)  made at
+ * models/layers.py:38 (MPNNLayerCat) and models/layers.py:110 (MPNNLayerSum), plus
+ * global_mean_pool(x, batch) at models/mpnn.py:54,150.  Each entry point below names
+ * the part of that call it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - every function returns 0 on success and a negative MPNN_E_* code otherwise;
+ *     mpnn_last_error() returns a thread-local description of the last failure;
+ *   - all work is enqueued on `stream`; no function synchronises the device, allocates
+ *     or frees device memory; scratch space is passed in by the caller
+ *     (sizes come from the *_workspace_bytes functions);
+ *   - dtype: MPNN_F32 (float) or MPNN_BF16 (bfloat16 storage, float accumulation);
+ *   - feature matrices are row-major with an explicit leading dimension `ld*` counted
+ *     in ELEMENTS, so the two halves of a [N,2H] fused projection can be passed
+ *     without a copy (models/layers.py:105, `fused_out.chunk(2, dim=1)`).
+ */
+#ifndef MPNN_AMD_H
+#define MPNN_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mpnn_stream_t; /* == hipStream_t */
+
+enum { MPNN_F32 = 0, MPNN_BF16 = 1 };
+
+enum {
+  MPNN_OK = 0,
+  MPNN_E_INVALID = -1,   /* bad argument (null pointer, size, alignment, unsupported shape) */
+  MPNN_E_WORKSPACE = -2, /* workspace too small */
+  MPNN_E_HIP = -3,       /* a HIP runtime call or kernel launch failed */
+  MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
+};
+
+#define MPNN_ABI_VERSION 1
+
+/* Library self-description. */
+int32_t mpnn_abi_version(void);
+const char* mpnn_last_error(void);
+
+/* ---------------------------------------------------------------------------
+ * Graph structure (integer-exact).
+ *
+ * Replaces the implicit index handling inside PyG's propagate():
+ * `index_select(·, 0, edge_index[0|1])` and `scatter_add_(0, edge_index[1], ·)`
+ * (call sites models/layers.py:38,110).
+ *
+ * mpnn_csr_build sorts the edge list by `key` (stable: edges with equal key keep
+ * their original order) and produces
+ *     rowptr[num_keys+1]  first sorted position of every key value (int32)
+ *     col[E]       `other` of the edge at each sorted position      (int32)
+ *     eid[E]       original edge id at each sorted position         (int32)
+ * Call it with (key=dst=edge_index[1], other=src=edge_index[0]) for the
+ * destination-sorted CSR the forward pass walks, and with the roles swapped for
+ * the source-sorted transpose the backward pass walks.
+ * Keys must lie in [0, num_keys) and `other` values in [0, num_other) (the two differ
+ * when a rank owns only a range of destination rows but reads every source row).
+ * status[0] is zeroed, then set to 1 on the device if any value is out of range; such
+ * edges are still placed (clamped) so no access is out of bounds, and the caller is
+ * expected to read status back and raise.
+ * Limits: num_keys, num_other, E < 2^31.
+ * ------------------------------------------------------------------------- */
+int64_t mpnn_csr_workspace_bytes(int64_t num_keys, int64_t num_edges);
+int32_t mpnn_csr_build(const int64_t* key, const int64_t* other, int64_t num_edges,
+                       int64_t num_keys, int64_t num_other, int32_t* rowptr, int32_t* col,
+                       int32_t* eid, int32_t* status, void* workspace, int64_t workspace_bytes,
+                       mpnn_stream_t stream);
+
+/* Work decomposition of a CSR into items of bounded length.
+ *
+ * A row with deg <= chunk is one item; a longer row is cut into pieces of
+ * max(chunk, ceil(deg / max_parts)) edges whose partial sums are combined in piece
+ * order afterwards (fixed order => bitwise reproducible results, no atomics).
+ *   items[4*t .. 4*t+3] = { row, e0, e1, pslot }   pslot = -1 for an unsplit row,
+ *                                                    else the piece's partial-sum slot
+ *   split[4*s .. 4*s+3] = { row, first pslot, pieces, first item }
+ *   meta[0..2]          = { number of items, number of partial slots, number of split rows }
+ * Items of split rows come first, then unsplit rows in row order.
+ * Capacity needed: items <= N + E/chunk + 1 ; split <= E/(chunk+1) + 1.
+ */
+int64_t mpnn_items_workspace_bytes(int64_t num_nodes);
+int32_t mpnn_items_build(const int32_t* rowptr, int64_t num_nodes, int32_t chunk,
+                         int32_t max_parts, int32_t* items, int64_t items_capacity,
+                         int32_t* split, int64_t split_capacity, int32_t* meta,
+                         void* workspace, int64_t workspace_bytes, mpnn_stream_t stream);
+
+/* dst[r, :] = src[index[r], :] for rows of `row_bytes` bytes (row_bytes % 2 == 0).
+ * Used to lay edge_attr out in CSR order once per graph (eid / eid_t from above). */
+int32_t mpnn_gather_rows(const void* src, const int32_t* index, void* dst, int64_t rows,
+                         int64_t row_bytes, mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused message + sum aggregation, forward.
+ *
+ * Replaces, for one layer, PyG's gather -> message() -> scatter_add_ chain:
+ *   models/layers.py:128  relu((xs_i + xt_j) + es)           (MPNNLayerSum.message)
+ *   models/layers.py:56   relu(W [x_i | x_j | e])            (MPNNLayerCat.message, after
+ *                         splitting W column-wise into W_i, W_j, W_e and projecting nodes first)
+ *   models/layers.py:108  es = linear_3(edge_attr)           (recomputed per edge in registers)
+ *   aggr='add'            models/layers.py:20,82
+ *
+ *   out[n, :] = sum_{p in [rowptr[n], rowptr[n+1])}
+ *                  relu((A[n, :] + B[col[p], :]) + We @ ea_sorted[p, :])
+ *
+ * A, B      [N, H] with leading dimensions ldA, ldB (elements)
+ * ea_sorted [E, Fe] edge attributes ALREADY in CSR order (see mpnn_gather_rows)
+ * We        [H, Fe] row-major (the Linear weight layout), same dtype as A
+ * items/split/n_*  from mpnn_items_build for this CSR
+ * out       [N, H] leading dimension ldo
+ * cnt       optional float [N, H]: number of edges of row n whose message is > 0 in
+ *           column h (needed by the backward: d out / d A = grad * cnt); may be NULL
+ * part_out, part_cnt  float [n_parts, H] scratch for split rows (part_cnt may be NULL
+ *           iff cnt is NULL); may be NULL when n_parts == 0
+ * Requirements: H % 4 == 0 (f32) or H % 8 == 0 (bf16) for the vector path, otherwise a
+ * scalar path is used; base pointers 16-byte aligned and ld* % vector width == 0 for
+ * the vector path. 1 <= Fe <= 8.
+ * ------------------------------------------------------------------------- */
+int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB,
+                           const void* ea_sorted, int32_t Fe, const void* We,
+                           const int32_t* col, const int32_t* items, int64_t n_items,
+                           const int32_t* split, int64_t n_split, int64_t n_parts,
+                           void* out, int64_t ldo, float* cnt, float* part_out,
+                           float* part_cnt, int64_t num_nodes, int32_t H, int32_t dtype,
+                           mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Backward of the aggregation with respect to B (the per-source table) and We.
+ *
+ * Replaces what autograd derives for the chain above (triggered by loss.backward(),
+ * training/train.py:23,48,76): grad_msg = grad_aggr[dst]; masked by msg > 0;
+ * index_add_ by src; and grad of linear_3.
+ *
+ * Walks the SOURCE-sorted transpose (rowptr_t/col_t hold destination ids):
+ *   gB[s, :]  = sum_{p in row s} mask_p * G[col_t[p], :]
+ *   gWe[h, f] = sum_p mask_p[h] * G[col_t[p], h] * ea_sorted_t[p, f]
+ *   mask_p    = ((A[col_t[p], :] + B[s, :]) + We @ ea_sorted_t[p, :]) > 0
+ * The gradient with respect to A needs no edge pass: gA = G * cnt (elementwise).
+ *
+ * G            [Nd, H] gradient of the loss w.r.t. `out` of the forward (ldG)
+ * ea_sorted_t  [E, Fe] edge attributes in TRANSPOSE order
+ * gB           [Ns, H] (ldgB)
+ * gWe          [H, Fe] same dtype as A
+ * part_gB      float [n_parts, H] scratch for split rows (NULL when n_parts == 0)
+ * gwe_scratch  float, at least mpnn_bwd_scratch_floats(H, Fe) elements
+ * ------------------------------------------------------------------------- */
+int64_t mpnn_bwd_scratch_floats(int32_t H, int32_t Fe);
+int32_t mpnn_aggregate_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB,
+                               const void* G, int64_t ldG, const void* ea_sorted_t,
+                               int32_t Fe, const void* We, const int32_t* col_t,
+                               const int32_t* items_t, int64_t n_items_t,
+                               const int32_t* split_t, int64_t n_split_t, int64_t n_parts_t,
+                               void* gB, int64_t ldgB, void* gWe, float* part_gB,
+                               float* gwe_scratch, int64_t num_src_nodes, int32_t H,
+                               int32_t dtype, mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Segment mean over an index list: out[g, :] = (1/max(cnt_g,1)) * sum_{p in seg g} x[col[p], :]
+ * and its backward gx[col[p], :] = gout[g, :] / max(cnt_g, 1).
+ *
+ * Replaces global_mean_pool(x, batch) at models/mpnn.py:54,150.  The CSR is built
+ * with mpnn_csr_build(key = batch, other = arange(N)), so unsorted `batch` works too.
+ * ------------------------------------------------------------------------- */
+int32_t mpnn_segment_mean_fwd(const void* x, int64_t ldx, const int32_t* rowptr,
+                              const int32_t* col, void* out, int64_t ldo,
+                              int64_t num_segments, int32_t H, int32_t dtype,
+                              mpnn_stream_t stream);
+int32_t mpnn_segment_mean_bwd(const void* gout, int64_t ldg, const int32_t* rowptr,
+                              const int32_t* col, void* gx, int64_t ldgx,
+                              int64_t num_segments, int32_t H, int32_t dtype,
+                              mpnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPNN_AMD_H */

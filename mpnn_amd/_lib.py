@@ -1,0 +1,104 @@
+"""ctypes binding of libmpnn_amd.so (the C ABI declared in include/mpnn_amd.h).
+
+The library is the product: there is no fallback.  If it is missing or an entry point
+fails, the caller gets an exception carrying the library's own error text.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_int32, c_int64, c_void_p
+
+import torch  # noqa: F401  (loads the HIP runtime the library binds to)
+
+MPNN_F32 = 0
+MPNN_BF16 = 1
+ABI_VERSION = 1
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
+
+# name -> (restype, argtypes); mirrors include/mpnn_amd.h one to one.
+SIGNATURES = {
+    "mpnn_abi_version": (c_int32, []),
+    "mpnn_last_error": (c_char_p, []),
+    "mpnn_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "mpnn_csr_build": (c_int32, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpnn_items_workspace_bytes": (c_int64, [c_int64]),
+    "mpnn_items_build": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpnn_gather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "mpnn_aggregate_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
+                                     c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                     c_void_p]),
+    "mpnn_bwd_scratch_floats": (c_int64, [c_int32, c_int32]),
+    "mpnn_aggregate_bwd_src": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                         c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                         c_int32, c_int32, c_void_p]),
+    "mpnn_segment_mean_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                        c_int32, c_int32, c_void_p]),
+    "mpnn_segment_mean_bwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                        c_int32, c_int32, c_void_p]),
+}
+
+
+class MpnnError(RuntimeError):
+    """An entry point of libmpnn_amd.so returned a non-zero status."""
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library once; raises if it is absent or of another ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpnnError(
+            f"{LIB_PATH} not found: build it with `make -C mpnn_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU or PyTorch fallback for the message-passing path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.mpnn_abi_version()
+    if got != ABI_VERSION:
+        raise MpnnError(f"libmpnn_amd.so has ABI version {got}, this package needs {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().mpnn_last_error()
+        raise MpnnError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int | None:
+    """Device address of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_handle(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dtype_code(dtype) -> int:
+    if dtype == torch.float32:
+        return MPNN_F32
+    if dtype == torch.bfloat16:
+        return MPNN_BF16
+    raise TypeError(f"mpnn_amd supports float32 and bfloat16 features, got {dtype}")
+
+
+def require_device(t, name: str) -> None:
+    if not t.is_cuda:
+        raise MpnnError(
+            f"{name} is on {t.device}: the message-passing engine runs on an AMD GPU only "
+            "(there is no CPU path; the CPU oracle under oracle/ is test infrastructure).")

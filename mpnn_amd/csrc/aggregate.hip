@@ -1,0 +1,660 @@
+// Fused message + sum aggregation over a destination-sorted CSR, and its backward over the
+// source-sorted transpose, for gfx950 (wave64).
+//
+// Replaces, for one layer, the gather -> message() -> scatter_add_ chain that PyG's
+// MessagePassing.propagate() runs for the reference (call sites models/layers.py:38,110;
+// message bodies models/layers.py:56,128) and the autograd backward of that chain.
+//
+// Work layout
+//   * A feature row of H elements is owned by a GROUP of LPR = 2^k lanes (k chosen so that
+//     LPR * VEC >= min(H, 64 * VEC)); each lane moves VEC consecutive columns with one 16-byte
+//     access (4 floats or 8 bf16).  A wave holds 64 / LPR groups, a 256-thread block 4 waves.
+//   * A group walks one work item (a CSR row, or a bounded piece of a long row) edge by edge
+//     and keeps the running sum in registers, so the sum order inside an item is the CSR
+//     (= original edge) order and no atomics are needed.  Pieces of a split row go to a
+//     float scratch slab and are combined in piece order by k_reduce_split.
+//   * Source indices of an item are fetched LPR at a time with one coalesced load and handed
+//     round the group with ds_bpermute; U row gathers per lane are kept in flight.
+#include "common.h"
+#include "rowio.h"
+
+namespace mpnn {
+
+constexpr int kMaxFe = 8;  // edge-attribute width handled by the generic (runtime Fe) instantiation
+
+// VEC floats to a float row; 16-byte stores when the lane owns a multiple of 4 columns.
+template <int VEC>
+__device__ __forceinline__ void store_f32(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q)
+      reinterpret_cast<float4*>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) p[q] = v[q];
+  }
+}
+
+// relu as the reference computes it: NaN propagates, 0 for x <= 0.
+__device__ __forceinline__ float relu_f(float x) { return x <= 0.f ? 0.f : x; }
+
+template <typename T>
+struct FwdArgs {
+  const T* A; int64_t ldA;
+  const T* B; int64_t ldB;
+  const T* ea; int fe;
+  const T* We;
+  const int32_t* col;
+  const int4* items; int64_t n_items;
+  T* out; int64_t ldo;
+  float* cnt;
+  float* part_out;
+  float* part_cnt;
+  int H; int lpr_log2;
+};
+
+// Per-lane weights of the edge projection: w[v][f] = We[c0 + v][f].
+template <typename T, int VEC, int FE>
+__device__ __forceinline__ void load_edge_weights(const T* We, int fe, int c0, bool act, float (&w)[VEC][FE]) {
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+#pragma unroll
+    for (int f = 0; f < FE; ++f)
+      w[v][f] = (act && f < fe) ? scalar_to_f32<T>(We[(int64_t)(c0 + v) * fe + f]) : 0.f;
+}
+
+template <typename T, int FE, bool RTFE>
+__device__ __forceinline__ void load_edge_attr(const T* ea, int64_t p, int fe, float (&e)[FE]) {
+  if constexpr (RTFE) {
+#pragma unroll
+    for (int f = 0; f < FE; ++f) e[f] = f < fe ? scalar_to_f32<T>(ea[p * fe + f]) : 0.f;
+  } else {
+    EdgeIO<T, FE>::load(ea + p * FE, e);
+  }
+}
+
+// ce[v] = sum_f w[v][f] * e[f], as an explicit fma chain in f order.
+template <int VEC, int FE>
+__device__ __forceinline__ void edge_term(const float (&w)[VEC][FE], const float (&e)[FE], float (&ce)[VEC]) {
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    float s = w[v][0] * e[0];
+#pragma unroll
+    for (int f = 1; f < FE; ++f) s = fmaf(w[v][f], e[f], s);
+    ce[v] = s;
+  }
+}
+
+template <typename T, int VEC, int FE, bool RTFE, bool TRAIN, int U>
+__global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int lig = lane & (lpr - 1);
+  const int grp = lane >> a.lpr_log2;
+  const int gpw = 64 >> a.lpr_log2;
+  const int c0 = blockIdx.y * (lpr * VEC) + lig * VEC;
+  const bool act = c0 < a.H;
+  const int cc = act ? c0 : 0;  // inactive lanes shadow column 0 and never store
+
+  float w[VEC][FE];
+  load_edge_weights<T, VEC, FE>(a.We, a.fe, c0, act, w);
+
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 64) * gpw;
+  for (int64_t tb = wave * gpw; tb < a.n_items; tb += stride) {
+    const int64_t t = tb + grp;
+    const bool valid = t < a.n_items;
+    int4 it = valid ? a.items[t] : make_int4(0, 0, 0, -1);
+    const int row = it.x, e0 = it.y, e1 = it.z;
+
+    float ar[VEC], acc[VEC], cn[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { ar[v] = 0.f; acc[v] = 0.f; cn[v] = 0.f; }
+    if (valid) RowIO<T, VEC>::load(a.A + (int64_t)row * a.ldA + cc, ar);
+
+    int nxt = (e0 + lig < e1) ? a.col[e0 + lig] : 0;
+    for (int base = e0; base < e1; base += lpr) {
+      const int cur = nxt;
+      const int nb = (e1 - base) < lpr ? (e1 - base) : lpr;
+      const int pn = base + lpr + lig;
+      nxt = pn < e1 ? a.col[pn] : 0;
+      for (int j = 0; j < nb; j += U) {
+        float bv[U][VEC], ev[U][FE];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jj = (j + u) < nb ? (j + u) : (nb - 1);
+          const int s = __shfl(cur, jj, lpr);
+          RowIO<T, VEC>::load(a.B + (int64_t)s * a.ldB + cc, bv[u]);
+          load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(base + jj), a.fe, ev[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool live = (j + u) < nb;
+          float ce[VEC];
+          edge_term<VEC, FE>(w, ev[u], ce);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            float m = relu_f((ar[v] + bv[u][v]) + ce[v]);
+            m = live ? m : 0.f;
+            acc[v] += m;
+            if (TRAIN) cn[v] += (m > 0.f) ? 1.f : 0.f;
+          }
+        }
+      }
+    }
+
+    if (valid && act) {
+      if (it.w < 0) {
+        RowIO<T, VEC>::store(a.out + (int64_t)row * a.ldo + c0, acc);
+        if (TRAIN) store_f32<VEC>(a.cnt + (int64_t)row * a.H + c0, cn);
+      } else {
+        float* po = a.part_out + (int64_t)it.w * a.H + c0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) po[v] = acc[v];
+        if (TRAIN) {
+          float* pc = a.part_cnt + (int64_t)it.w * a.H + c0;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pc[v] = cn[v];
+        }
+      }
+    }
+  }
+}
+
+// Combine the pieces of split rows in piece order.  One wave per split row: group g adds
+// pieces g, g + gpw, ... in order, then the groups' sums are added in group order.
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock) k_reduce_split(const float* __restrict__ parts, const int4* __restrict__ split,
+                                                         int64_t n_split, T* __restrict__ out, int64_t ldo, int H,
+                                                         int lpr_log2) {
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << lpr_log2;
+  const int lig = lane & (lpr - 1);
+  const int grp = lane >> lpr_log2;
+  const int gpw = 64 >> lpr_log2;
+  const int c0 = blockIdx.y * (lpr * VEC) + lig * VEC;
+  const bool act = c0 < H;
+  const int cc = act ? c0 : 0;
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
+  for (int64_t s = wave; s < n_split; s += nwaves) {
+    const int4 sr = split[s];
+    const int row = sr.x, poff = sr.y, pieces = sr.z;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int c = grp; c < pieces; c += gpw) {
+      const float* p = parts + (int64_t)(poff + c) * H + cc;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += p[v];
+    }
+    float tot[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) tot[v] = 0.f;
+    for (int g = 0; g < gpw; ++g) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) tot[v] += __shfl(acc[v], g * lpr + lig, 64);
+    }
+    if (grp == 0 && act) {
+      T* o = out + (int64_t)row * ldo + c0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) o[v] = f32_to_scalar<T>(tot[v]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward over the source-sorted transpose.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+struct BwdArgs {
+  const T* A; int64_t ldA;
+  const T* B; int64_t ldB;
+  const T* G; int64_t ldG;
+  const T* ea; int fe;
+  const T* We;
+  const int32_t* col;
+  const int4* items; int64_t n_items;
+  T* gB; int64_t ldgB;
+  float* part_gB;
+  float* gwe_partial;  // [gridDim.x][H][fe]
+  int H; int lpr_log2;
+};
+
+template <typename T, int VEC, int FE, bool RTFE, int U>
+__global__ void __launch_bounds__(kBlock) k_agg_bwd_src(BwdArgs<T> a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int lpr = 1 << a.lpr_log2;
+  const int lig = lane & (lpr - 1);
+  const int grp = lane >> a.lpr_log2;
+  const int gpw = 64 >> a.lpr_log2;
+  const int tile = lpr * VEC;
+  const int c0 = blockIdx.y * tile + lig * VEC;
+  const bool act = c0 < a.H;
+  const int cc = act ? c0 : 0;
+
+  float w[VEC][FE], gw[VEC][FE];
+  load_edge_weights<T, VEC, FE>(a.We, a.fe, c0, act, w);
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+#pragma unroll
+    for (int f = 0; f < FE; ++f) gw[v][f] = 0.f;
+
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + wid;
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 64) * gpw;
+  for (int64_t tb = wave * gpw; tb < a.n_items; tb += stride) {
+    const int64_t t = tb + grp;
+    const bool valid = t < a.n_items;
+    int4 it = valid ? a.items[t] : make_int4(0, 0, 0, -1);
+    const int row = it.x, e0 = it.y, e1 = it.z;
+
+    float br[VEC], acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { br[v] = 0.f; acc[v] = 0.f; }
+    if (valid) RowIO<T, VEC>::load(a.B + (int64_t)row * a.ldB + cc, br);
+
+    int nxt = (e0 + lig < e1) ? a.col[e0 + lig] : 0;
+    for (int base = e0; base < e1; base += lpr) {
+      const int cur = nxt;
+      const int nb = (e1 - base) < lpr ? (e1 - base) : lpr;
+      const int pn = base + lpr + lig;
+      nxt = pn < e1 ? a.col[pn] : 0;
+      for (int j = 0; j < nb; j += U) {
+        float av[U][VEC], gv[U][VEC], ev[U][FE];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jj = (j + u) < nb ? (j + u) : (nb - 1);
+          const int d = __shfl(cur, jj, lpr);
+          RowIO<T, VEC>::load(a.A + (int64_t)d * a.ldA + cc, av[u]);
+          RowIO<T, VEC>::load(a.G + (int64_t)d * a.ldG + cc, gv[u]);
+          load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(base + jj), a.fe, ev[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool live = (j + u) < nb;
+          float ce[VEC];
+          edge_term<VEC, FE>(w, ev[u], ce);
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float pre = (av[u][v] + br[v]) + ce[v];
+            const float m = (live && pre > 0.f) ? gv[u][v] : 0.f;
+            acc[v] += m;
+#pragma unroll
+            for (int f = 0; f < FE; ++f) gw[v][f] = fmaf(m, ev[u][f], gw[v][f]);
+          }
+        }
+      }
+    }
+
+    if (valid && act) {
+      if (it.w < 0) {
+        RowIO<T, VEC>::store(a.gB + (int64_t)row * a.ldgB + c0, acc);
+      } else {
+        float* po = a.part_gB + (int64_t)it.w * a.H + c0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) po[v] = acc[v];
+      }
+    }
+  }
+
+  // Block-level sum of the edge-weight gradient in a fixed order: groups of a wave by
+  // ds_bpermute in group order, then the 4 waves through LDS in wave order.
+  // lds layout: [wave][tile column][FE]
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+#pragma unroll
+    for (int f = 0; f < FE; ++f) {
+      float tot = 0.f;
+      for (int g = 0; g < gpw; ++g) tot += __shfl(gw[v][f], g * lpr + lig, 64);
+      if (grp == 0) lds[(wid * tile + lig * VEC + v) * FE + f] = tot;
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tile * FE; i += kBlock) {
+    const int c = blockIdx.y * tile + i / FE;
+    const int f = i % FE;
+    if (c < a.H && f < a.fe) {
+      float tot = 0.f;
+      for (int k = 0; k < kBlock / 64; ++k) tot += lds[k * tile * FE + i];
+      a.gwe_partial[((int64_t)blockIdx.x * a.H + c) * a.fe + f] = tot;
+    }
+  }
+}
+
+// gWe[i] = sum over blocks of partial[b][i], b ascending: 256 threads take strided subsets
+// sequentially, then a fixed-shape tree in LDS.
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_reduce_gwe(const float* __restrict__ partial, int nblocks, int count,
+                                                       T* __restrict__ gWe) {
+  __shared__ float red[kBlock];
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += kBlock) s += partial[(int64_t)b * count + i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gWe[i] = f32_to_scalar<T>(red[0]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Segment mean (global_mean_pool, models/mpnn.py:54,150): one block per segment.
+// ---------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock) k_segment_mean_fwd(const T* __restrict__ x, int64_t ldx,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col, T* __restrict__ out,
+                                                             int64_t ldo, int64_t nseg, int H, int lpr_log2) {
+  extern __shared__ float lds[];
+  const int lpr = 1 << lpr_log2;
+  const int lig = threadIdx.x & (lpr - 1);
+  const int grp = threadIdx.x >> lpr_log2;
+  const int ngrp = kBlock >> lpr_log2;
+  const int tile = lpr * VEC;
+  const int c0 = blockIdx.y * tile + lig * VEC;
+  const bool act = c0 < H;
+  const int cc = act ? c0 : 0;
+  for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const int r0 = rowptr[s], r1 = rowptr[s + 1];
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int p = r0 + grp; p < r1; p += ngrp) {
+      float xv[VEC];
+      RowIO<T, VEC>::load(x + (int64_t)col[p] * ldx + cc, xv);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[v] += xv[v];
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) lds[grp * tile + lig * VEC + v] = acc[v];
+    __syncthreads();
+    if (grp == 0 && act) {
+      float tot[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) tot[v] = 0.f;
+      for (int g = 0; g < ngrp; ++g)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) tot[v] += lds[g * tile + lig * VEC + v];
+      const float cnt = (float)((r1 - r0) > 1 ? (r1 - r0) : 1);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) tot[v] = tot[v] / cnt;
+      RowIO<T, VEC>::store(out + s * ldo + c0, tot);
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(kBlock) k_segment_mean_bwd(const T* __restrict__ gout, int64_t ldg,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col, T* __restrict__ gx,
+                                                             int64_t ldgx, int64_t nseg, int H, int lpr_log2) {
+  const int lpr = 1 << lpr_log2;
+  const int lig = threadIdx.x & (lpr - 1);
+  const int grp = threadIdx.x >> lpr_log2;
+  const int ngrp = kBlock >> lpr_log2;
+  const int c0 = blockIdx.y * (lpr * VEC) + lig * VEC;
+  if (c0 >= H) return;
+  for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    const int r0 = rowptr[s], r1 = rowptr[s + 1];
+    if (r1 <= r0) continue;
+    float g[VEC];
+    RowIO<T, VEC>::load(gout + s * ldg + c0, g);
+    const float cnt = (float)(r1 - r0);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) g[v] = g[v] / cnt;
+    for (int p = r0 + grp; p < r1; p += ngrp) RowIO<T, VEC>::store(gx + (int64_t)col[p] * ldgx + c0, g);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Host-side dispatch
+// ---------------------------------------------------------------------------------------
+struct Geometry {
+  int vec;       // columns per lane
+  int lpr_log2;  // log2 lanes per row group
+  int tiles;     // column tiles (gridDim.y)
+};
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Chooses the vector path when every row access of every listed matrix is 16-byte aligned.
+static Geometry geometry(int H, int dtype, bool vec_ok) {
+  Geometry g;
+  const int full = dtype == MPNN_BF16 ? 8 : 4;
+  g.vec = (vec_ok && H % full == 0) ? full : 1;
+  int lanes = (H + g.vec - 1) / g.vec;
+  int k = 0;
+  while ((1 << k) < lanes && k < 6) ++k;
+  g.lpr_log2 = k;
+  const int tile = (1 << k) * g.vec;
+  g.tiles = (H + tile - 1) / tile;
+  return g;
+}
+
+static int row_grid(int64_t n_items, int lpr_log2) {
+  const int per_block = (kBlock / 64) * (64 >> lpr_log2);
+  int64_t g = (n_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > kMaxBlocks) g = kMaxBlocks;
+  return (int)g;
+}
+
+template <typename T, int VEC, bool TRAIN>
+static int32_t launch_fwd(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
+  constexpr int U = 4;
+  if (a.fe == 4) k_agg_fwd<T, VEC, 4, false, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
+  else if (a.fe == 1) k_agg_fwd<T, VEC, 1, false, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
+  else k_agg_fwd<T, VEC, kMaxFe, true, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
+  MPNN_LAUNCH_CHECK("k_agg_fwd");
+  return MPNN_OK;
+}
+
+template <typename T, int VEC>
+static int32_t launch_reduce_split(const float* parts, const int32_t* split, int64_t n_split, T* out, int64_t ldo,
+                                   int H, const Geometry& g, hipStream_t stream) {
+  int64_t blocks = (n_split + 3) / 4;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  k_reduce_split<T, VEC><<<dim3((unsigned)blocks, g.tiles), kBlock, 0, stream>>>(
+      parts, reinterpret_cast<const int4*>(split), n_split, out, ldo, H, g.lpr_log2);
+  MPNN_LAUNCH_CHECK("k_reduce_split");
+  return MPNN_OK;
+}
+
+template <typename T, int VEC>
+static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea, int32_t Fe,
+                       const void* We, const int32_t* col, const int32_t* items, int64_t n_items,
+                       const int32_t* split, int64_t n_split, void* out, int64_t ldo, float* cnt, float* part_out,
+                       float* part_cnt, int32_t H, const Geometry& g, hipStream_t stream) {
+  FwdArgs<T> a;
+  a.A = static_cast<const T*>(A); a.ldA = ldA;
+  a.B = static_cast<const T*>(B); a.ldB = ldB;
+  a.ea = static_cast<const T*>(ea); a.fe = Fe;
+  a.We = static_cast<const T*>(We);
+  a.col = col;
+  a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
+  a.out = static_cast<T*>(out); a.ldo = ldo;
+  a.cnt = cnt; a.part_out = part_out; a.part_cnt = part_cnt;
+  a.H = H; a.lpr_log2 = g.lpr_log2;
+  dim3 grid(row_grid(n_items, g.lpr_log2), g.tiles);
+  int32_t rc = cnt ? launch_fwd<T, VEC, true>(a, grid, stream) : launch_fwd<T, VEC, false>(a, grid, stream);
+  if (rc != MPNN_OK) return rc;
+  if (n_split > 0) {
+    rc = launch_reduce_split<T, VEC>(part_out, split, n_split, static_cast<T*>(out), ldo, H, g, stream);
+    if (rc != MPNN_OK) return rc;
+    if (cnt) rc = launch_reduce_split<float, VEC>(part_cnt, split, n_split, cnt, H, H, g, stream);
+  }
+  return rc;
+}
+
+template <typename T, int VEC>
+static int32_t run_bwd(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* G, int64_t ldG,
+                       const void* ea, int32_t Fe, const void* We, const int32_t* col, const int32_t* items,
+                       int64_t n_items, const int32_t* split, int64_t n_split, void* gB, int64_t ldgB, void* gWe,
+                       float* part_gB, float* scratch, int32_t H, const Geometry& g, hipStream_t stream) {
+  constexpr int U = 2;
+  BwdArgs<T> a;
+  a.A = static_cast<const T*>(A); a.ldA = ldA;
+  a.B = static_cast<const T*>(B); a.ldB = ldB;
+  a.G = static_cast<const T*>(G); a.ldG = ldG;
+  a.ea = static_cast<const T*>(ea); a.fe = Fe;
+  a.We = static_cast<const T*>(We);
+  a.col = col;
+  a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
+  a.gB = static_cast<T*>(gB); a.ldgB = ldgB;
+  a.part_gB = part_gB; a.gwe_partial = scratch;
+  a.H = H; a.lpr_log2 = g.lpr_log2;
+  dim3 grid(row_grid(n_items, g.lpr_log2), g.tiles);
+  const int tile = (1 << g.lpr_log2) * VEC;
+  const int fe_t = Fe == 4 ? 4 : (Fe == 1 ? 1 : kMaxFe);
+  const size_t lds = (size_t)(kBlock / 64) * tile * fe_t * sizeof(float);
+  if (Fe == 4) k_agg_bwd_src<T, VEC, 4, false, U><<<grid, kBlock, lds, stream>>>(a);
+  else if (Fe == 1) k_agg_bwd_src<T, VEC, 1, false, U><<<grid, kBlock, lds, stream>>>(a);
+  else k_agg_bwd_src<T, VEC, kMaxFe, true, U><<<grid, kBlock, lds, stream>>>(a);
+  MPNN_LAUNCH_CHECK("k_agg_bwd_src");
+  if (n_split > 0) {
+    int32_t rc = launch_reduce_split<T, VEC>(part_gB, split, n_split, static_cast<T*>(gB), ldgB, H, g, stream);
+    if (rc != MPNN_OK) return rc;
+  }
+  k_reduce_gwe<T><<<H * Fe, kBlock, 0, stream>>>(scratch, (int)grid.x, H * Fe, static_cast<T*>(gWe));
+  MPNN_LAUNCH_CHECK("k_reduce_gwe");
+  return MPNN_OK;
+}
+
+template <typename T, int VEC>
+static int32_t run_segmean(bool fwd, const void* in, int64_t ldin, const int32_t* rowptr, const int32_t* col,
+                           void* out, int64_t ldout, int64_t nseg, int32_t H, const Geometry& g, hipStream_t stream) {
+  int64_t blocks = nseg > kMaxBlocks ? kMaxBlocks : nseg;
+  dim3 grid((unsigned)blocks, g.tiles);
+  if (fwd) {
+    const size_t lds = (size_t)(kBlock >> g.lpr_log2) * (1 << g.lpr_log2) * VEC * sizeof(float);
+    k_segment_mean_fwd<T, VEC><<<grid, kBlock, lds, stream>>>(static_cast<const T*>(in), ldin, rowptr, col,
+                                                              static_cast<T*>(out), ldout, nseg, H, g.lpr_log2);
+  } else {
+    k_segment_mean_bwd<T, VEC><<<grid, kBlock, 0, stream>>>(static_cast<const T*>(in), ldin, rowptr, col,
+                                                            static_cast<T*>(out), ldout, nseg, H, g.lpr_log2);
+  }
+  MPNN_LAUNCH_CHECK("k_segment_mean");
+  return MPNN_OK;
+}
+
+static int32_t segmean(bool fwd, const void* in, int64_t ldin, const int32_t* rowptr, const int32_t* col, void* out,
+                       int64_t ldout, int64_t nseg, int32_t H, int32_t dtype, hipStream_t stream) {
+  if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "mpnn_segment_mean: dtype %d", dtype);
+  if (H < 1 || nseg < 0) return fail(MPNN_E_INVALID, "mpnn_segment_mean: H=%d nseg=%lld", H, (long long)nseg);
+  if (nseg == 0) return MPNN_OK;
+  if (!in || !rowptr || !col || !out) return fail(MPNN_E_INVALID, "mpnn_segment_mean: null pointer argument");
+  if (ldin < H || ldout < H) return fail(MPNN_E_INVALID, "mpnn_segment_mean: leading dimension below H");
+  const int full = dtype == MPNN_BF16 ? 8 : 4;
+  const bool vec_ok = aligned16(in) && aligned16(out) && ldin % full == 0 && ldout % full == 0;
+  const Geometry g = geometry(H, dtype, vec_ok);
+  if (dtype == MPNN_F32) {
+    if (g.vec == 4) return run_segmean<float, 4>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
+    return run_segmean<float, 1>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
+  }
+  if (g.vec == 8) return run_segmean<bf16_t, 8>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
+  return run_segmean<bf16_t, 1>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" {
+
+int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea_sorted, int32_t Fe,
+                           const void* We, const int32_t* col, const int32_t* items, int64_t n_items,
+                           const int32_t* split, int64_t n_split, int64_t n_parts, void* out, int64_t ldo, float* cnt,
+                           float* part_out, float* part_cnt, int64_t num_nodes, int32_t H, int32_t dtype,
+                           mpnn_stream_t stream) {
+  if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: dtype %d", dtype);
+  if (H < 1 || Fe < 1 || Fe > kMaxFe)
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: H=%d (>=1), Fe=%d (1..%d)", H, Fe, kMaxFe);
+  if (num_nodes < 0 || n_items < 0 || n_split < 0 || n_parts < 0)
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: negative size");
+  if (num_nodes == 0 || n_items == 0) return MPNN_OK;
+  if (!A || !B || !We || !items || !out) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: null pointer argument");
+  if (ldA < H || ldB < H || ldo < H) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: leading dimension below H");
+  if (n_parts > 0 && (!part_out || (cnt && !part_cnt) || !split))
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: split rows present but scratch slabs are null");
+  if (((uintptr_t)items & 15) || ((uintptr_t)split & 15))
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: items/split must be 16-byte aligned");
+  const int full = dtype == MPNN_BF16 ? 8 : 4;
+  const bool vec_ok = aligned16(A) && aligned16(B) && aligned16(out) && aligned16(cnt) && aligned16(ea_sorted) &&
+                      ldA % full == 0 && ldB % full == 0 && ldo % full == 0;
+  const Geometry g = geometry(H, dtype, vec_ok);
+  if (dtype == MPNN_F32) {
+    if (g.vec == 4)
+      return run_fwd<float, 4>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
+                               part_out, part_cnt, H, g, stream);
+    return run_fwd<float, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
+                             part_out, part_cnt, H, g, stream);
+  }
+  if (g.vec == 8)
+    return run_fwd<bf16_t, 8>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
+                              part_out, part_cnt, H, g, stream);
+  return run_fwd<bf16_t, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
+                            part_out, part_cnt, H, g, stream);
+}
+
+int64_t mpnn_bwd_scratch_floats(int32_t H, int32_t Fe) {
+  if (H < 1 || Fe < 1) return -1;
+  return (int64_t)kMaxBlocks * H * Fe;
+}
+
+int32_t mpnn_aggregate_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* G, int64_t ldG,
+                               const void* ea_sorted_t, int32_t Fe, const void* We, const int32_t* col_t,
+                               const int32_t* items_t, int64_t n_items_t, const int32_t* split_t, int64_t n_split_t,
+                               int64_t n_parts_t, void* gB, int64_t ldgB, void* gWe, float* part_gB,
+                               float* gwe_scratch, int64_t num_src_nodes, int32_t H, int32_t dtype,
+                               mpnn_stream_t stream) {
+  if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: dtype %d", dtype);
+  if (H < 1 || Fe < 1 || Fe > kMaxFe)
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: H=%d (>=1), Fe=%d (1..%d)", H, Fe, kMaxFe);
+  if (num_src_nodes < 0 || n_items_t < 0 || n_split_t < 0 || n_parts_t < 0)
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: negative size");
+  if (!gWe || !gwe_scratch) return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: gWe/gwe_scratch is null");
+  if (num_src_nodes == 0 || n_items_t == 0) {
+    MPNN_HIP_CHECK(hipMemsetAsync(gWe, 0, (size_t)H * Fe * (dtype == MPNN_BF16 ? 2 : 4), stream));
+    return MPNN_OK;
+  }
+  if (!A || !B || !G || !We || !items_t || !gB)
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: null pointer argument");
+  if (ldA < H || ldB < H || ldG < H || ldgB < H)
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: leading dimension below H");
+  if (n_parts_t > 0 && (!part_gB || !split_t))
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: split rows present but scratch slab is null");
+  if (((uintptr_t)items_t & 15) || ((uintptr_t)split_t & 15))
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: items/split must be 16-byte aligned");
+  const int full = dtype == MPNN_BF16 ? 8 : 4;
+  const bool vec_ok = aligned16(A) && aligned16(B) && aligned16(G) && aligned16(gB) && aligned16(ea_sorted_t) &&
+                      ldA % full == 0 && ldB % full == 0 && ldG % full == 0 && ldgB % full == 0;
+  const Geometry g = geometry(H, dtype, vec_ok);
+  if (dtype == MPNN_F32) {
+    if (g.vec == 4)
+      return run_bwd<float, 4>(A, ldA, B, ldB, G, ldG, ea_sorted_t, Fe, We, col_t, items_t, n_items_t, split_t,
+                               n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
+    return run_bwd<float, 1>(A, ldA, B, ldB, G, ldG, ea_sorted_t, Fe, We, col_t, items_t, n_items_t, split_t,
+                             n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
+  }
+  if (g.vec == 8)
+    return run_bwd<bf16_t, 8>(A, ldA, B, ldB, G, ldG, ea_sorted_t, Fe, We, col_t, items_t, n_items_t, split_t,
+                              n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
+  return run_bwd<bf16_t, 1>(A, ldA, B, ldB, G, ldG, ea_sorted_t, Fe, We, col_t, items_t, n_items_t, split_t,
+                            n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
+}
+
+int32_t mpnn_segment_mean_fwd(const void* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, void* out,
+                              int64_t ldo, int64_t num_segments, int32_t H, int32_t dtype, mpnn_stream_t stream) {
+  return segmean(true, x, ldx, rowptr, col, out, ldo, num_segments, H, dtype, stream);
+}
+
+int32_t mpnn_segment_mean_bwd(const void* gout, int64_t ldg, const int32_t* rowptr, const int32_t* col, void* gx,
+                              int64_t ldgx, int64_t num_segments, int32_t H, int32_t dtype, mpnn_stream_t stream) {
+  return segmean(false, gout, ldg, rowptr, col, gx, ldgx, num_segments, H, dtype, stream);
+}
+
+}  // extern "C"

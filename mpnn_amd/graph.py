@@ -1,0 +1,157 @@
+"""Graph structure on the device: destination-sorted CSR, source-sorted transpose, work items.
+
+Built once per ``edge_index`` tensor by the HIP library and cached on that tensor, so the
+unchanged training loops (which pass the same ``data.edge_index`` every step, reference
+training/train.py:46) pay for the sort once; mini-batch loops (training/train.py:96-98)
+pay per batch.
+"""
+from __future__ import annotations
+
+import collections
+
+import torch
+
+from . import _lib
+
+# Row-splitting rule of mpnn_items_build: rows longer than CHUNK edges are cut into at most
+# MAX_PARTS pieces of at least CHUNK edges.
+CHUNK = 64
+MAX_PARTS = 256
+
+
+class CSR:
+    """One sorted view of the edge list (see mpnn_csr_build / mpnn_items_build)."""
+
+    __slots__ = ("num_rows", "num_cols", "num_edges", "rowptr", "col", "eid", "items", "split",
+                 "n_items", "n_parts", "n_split")
+
+    def degree(self) -> torch.Tensor:
+        return self.rowptr[1:] - self.rowptr[:-1]
+
+
+def _build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: int,
+               chunk: int, max_parts: int) -> CSR:
+    lib = _lib.load()
+    dev = key.device
+    E = key.numel()
+    stream = _lib.stream_handle(dev)
+    csr = CSR()
+    csr.num_rows, csr.num_cols, csr.num_edges = num_rows, num_cols, E
+    csr.rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
+    csr.col = torch.empty(E, dtype=torch.int32, device=dev)
+    csr.eid = torch.empty(E, dtype=torch.int32, device=dev)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    ws_bytes = lib.mpnn_csr_workspace_bytes(num_rows, E)
+    if ws_bytes < 0:
+        raise _lib.MpnnError(f"mpnn_csr_workspace_bytes({num_rows}, {E}) failed")
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.check(lib.mpnn_csr_build(_lib.ptr(key), _lib.ptr(other), E, num_rows, num_cols, _lib.ptr(csr.rowptr),
+                                  _lib.ptr(csr.col), _lib.ptr(csr.eid), _lib.ptr(status), _lib.ptr(ws), ws.numel(),
+                                  stream), "mpnn_csr_build")
+
+    items_cap = num_rows + E // chunk + 1
+    split_cap = E // (chunk + 1) + 1
+    csr.items = torch.empty((items_cap, 4), dtype=torch.int32, device=dev)
+    csr.split = torch.empty((split_cap, 4), dtype=torch.int32, device=dev)
+    meta = torch.zeros(8, dtype=torch.int32, device=dev)
+    ws2_bytes = lib.mpnn_items_workspace_bytes(num_rows)
+    if ws2_bytes < 0:
+        raise _lib.MpnnError(f"mpnn_items_workspace_bytes({num_rows}) failed")
+    if ws2_bytes > ws.numel():
+        ws = torch.empty(ws2_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.mpnn_items_build(_lib.ptr(csr.rowptr), num_rows, chunk, max_parts, _lib.ptr(csr.items),
+                                    items_cap, _lib.ptr(csr.split), split_cap, _lib.ptr(meta), _lib.ptr(ws),
+                                    ws.numel(), stream), "mpnn_items_build")
+    # One host read per graph build: item counts and the range-check flag.
+    host = torch.cat([meta[:4], status[:1]]).tolist()
+    if host[4] != 0:
+        raise IndexError(f"edge_index holds node ids outside [0, {num_rows}) x [0, {num_cols})")
+    if host[3] != 0:
+        raise _lib.MpnnError("mpnn_items_build overflowed its output capacity")
+    csr.n_items, csr.n_parts, csr.n_split = host[0], host[1], host[2]
+    return csr
+
+
+class MPGraph:
+    """CSR by destination (forward) and by source (backward) of one ``edge_index``.
+
+    ``edge_index`` is int64 ``[2, E]``, row 0 = source, row 1 = target, unsorted, duplicates
+    allowed (PyG convention used by the reference, models/layers.py:38,110).
+    ``num_dst`` / ``num_src`` differ only for a rank-local piece of a partitioned graph.
+    """
+
+    def __init__(self, edge_index: torch.Tensor, num_dst: int, num_src: int | None = None,
+                 chunk: int = CHUNK, max_parts: int = MAX_PARTS):
+        _lib.require_device(edge_index, "edge_index")
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
+        if edge_index.dtype != torch.int64:
+            raise TypeError(f"edge_index must be int64, got {edge_index.dtype}")
+        num_src = num_dst if num_src is None else num_src
+        src = edge_index[0].contiguous()
+        dst = edge_index[1].contiguous()
+        self.num_dst, self.num_src, self.num_edges = int(num_dst), int(num_src), src.numel()
+        self.by_dst = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts)
+        self.by_src = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts)
+        self._ea_key = None
+        self._ea_sorted = None
+        self._scratch = {}
+
+    def sorted_edge_attr(self, edge_attr: torch.Tensor, dtype: torch.dtype):
+        """edge_attr laid out in CSR order and in transpose order (cached per tensor version)."""
+        key = (edge_attr.data_ptr(), edge_attr._version, tuple(edge_attr.shape), edge_attr.dtype, dtype)
+        if self._ea_key == key:
+            return self._ea_sorted
+        if edge_attr.dim() != 2 or edge_attr.size(0) != self.num_edges:
+            raise ValueError(f"edge_attr must have shape [{self.num_edges}, Fe], got {tuple(edge_attr.shape)}")
+        lib = _lib.load()
+        src = edge_attr.detach().to(dtype).contiguous()
+        row_bytes = src.size(1) * src.element_size()
+        outs = []
+        for csr in (self.by_dst, self.by_src):
+            out = torch.empty_like(src)
+            _lib.check(lib.mpnn_gather_rows(_lib.ptr(src), _lib.ptr(csr.eid), _lib.ptr(out), self.num_edges,
+                                            row_bytes, _lib.stream_handle(src.device)), "mpnn_gather_rows")
+            outs.append(out)
+        self._ea_key = key
+        self._ea_holder = edge_attr  # keeps the address from being reused while the cache entry lives
+        self._ea_sorted = tuple(outs)
+        return self._ea_sorted
+
+    def scratch(self, name: str, shape, dtype, device) -> torch.Tensor:
+        """Reusable scratch slabs (partial sums of split rows, gradient partials)."""
+        key = (name, tuple(shape), dtype)
+        buf = self._scratch.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=dtype, device=device)
+            self._scratch[key] = buf
+        return buf
+
+
+_CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
+_CACHE_SIZE = 8
+
+
+@torch.compiler.disable
+def graph_for(edge_index: torch.Tensor, num_nodes: int) -> MPGraph:
+    """Cached MPGraph of ``edge_index``.
+
+    The cache entry holds a reference to the tensor, so its storage address cannot be
+    recycled for another edge list while the entry is alive; an in-place edit bumps
+    ``_version`` and misses.
+    """
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
+           str(edge_index.device), int(num_nodes))
+    hit = _CACHE.get(key)
+    if hit is not None:
+        _CACHE.move_to_end(key)
+        return hit[1]
+    g = MPGraph(edge_index, num_nodes)
+    _CACHE[key] = (edge_index, g)
+    while len(_CACHE) > _CACHE_SIZE:
+        _CACHE.popitem(last=False)
+    return g
+
+
+def clear_cache() -> None:
+    _CACHE.clear()

@@ -1,0 +1,60 @@
+"""Model stacks with the reference's class names, constructor and forward signatures
+(reference models/mpnn.py:8-55 MPNN_QM9, :57-101 MPNN, :104-151 MPNN_ModelNet).
+
+Note the reference's argument order for the pooled models: forward(x, edge_index, batch, edge_attr).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch.nn import Linear
+
+from .layers import MPNNLayerCat, MPNNLayerSum
+from .ops import global_mean_pool
+
+
+def _make_layers(in_channels, edge_channels, hidden_channels, num_layers, mode):
+    cls = MPNNLayerCat if mode == 'cat' else MPNNLayerSum
+    layers = torch.nn.ModuleList()
+    layers.append(cls(in_channels, edge_channels, hidden_channels))
+    for _ in range(num_layers - 1):
+        layers.append(cls(hidden_channels, edge_channels, hidden_channels))
+    return layers
+
+
+class MPNN(torch.nn.Module):
+    """Node-level model (Flickr); edge_channels is fixed to 4 as in the reference (models/mpnn.py:72-81)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers=2, mode="cat"):
+        super().__init__()
+        self.layers = _make_layers(in_channels, 4, hidden_channels, num_layers, mode)
+        self.output_layer = Linear(hidden_channels, out_channels)
+
+    def forward(self, x, edge_index, edge_attr):
+        for layer in self.layers:
+            x = layer(x, edge_index, edge_attr)
+            x = F.relu(x)
+        return self.output_layer(x)
+
+
+class _PooledMPNN(torch.nn.Module):
+    def __init__(self, in_channels, edge_channels, hidden_channels, out_channels, num_layers=2, mode='cat'):
+        super().__init__()
+        print('Using cat' if mode == 'cat' else 'Using sum')  # models/mpnn.py:23,26,119,122
+        self.layers = _make_layers(in_channels, edge_channels, hidden_channels, num_layers, mode)
+        self.output_layer = Linear(hidden_channels, out_channels)
+
+    def forward(self, x, edge_index, batch, edge_attr):
+        for layer in self.layers:
+            x = layer(x, edge_index, edge_attr)
+            x = F.relu(x)
+        x = global_mean_pool(x, batch)
+        return self.output_layer(x)
+
+
+class MPNN_QM9(_PooledMPNN):
+    pass
+
+
+class MPNN_ModelNet(_PooledMPNN):
+    pass

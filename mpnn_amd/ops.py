@@ -1,0 +1,201 @@
+"""Autograd operators over the HIP library: fused message+aggregate and segment mean.
+
+``aggregate`` replaces the gather -> message -> scatter-add that PyG's
+``MessagePassing.propagate`` runs for the reference (models/layers.py:38,110) and the
+backward autograd derives for it; ``segment_mean`` replaces ``global_mean_pool``
+(models/mpnn.py:54,150).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from .graph import CSR, MPGraph, _build_csr, CHUNK, MAX_PARTS
+
+
+def _check_features(name, t, rows, H=None):
+    _lib.require_device(t, name)
+    if t.dim() != 2 or t.size(0) != rows or (H is not None and t.size(1) != H):
+        raise ValueError(f"{name} must have shape [{rows}, {H if H is not None else 'H'}], got {tuple(t.shape)}")
+    if t.stride(1) != 1:
+        raise ValueError(f"{name} must have unit stride along features, got strides {t.stride()}")
+
+
+def _run_forward(A, B, ea_sorted, We, csr: CSR, graph: MPGraph, want_cnt: bool):
+    lib = _lib.load()
+    N, H = A.shape
+    dev, dtype = A.device, A.dtype
+    out = torch.empty((N, H), dtype=dtype, device=dev)
+    cnt = torch.empty((N, H), dtype=torch.float32, device=dev) if want_cnt else None
+    part_out = part_cnt = None
+    if csr.n_parts > 0:
+        part_out = graph.scratch("part_out", (csr.n_parts, H), torch.float32, dev)
+        if want_cnt:
+            part_cnt = graph.scratch("part_cnt", (csr.n_parts, H), torch.float32, dev)
+    _lib.check(lib.mpnn_aggregate_fwd(
+        _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(ea_sorted), ea_sorted.size(1), _lib.ptr(We),
+        _lib.ptr(csr.col), _lib.ptr(csr.items), csr.n_items, _lib.ptr(csr.split), csr.n_split, csr.n_parts,
+        _lib.ptr(out), out.stride(0), _lib.ptr(cnt), _lib.ptr(part_out), _lib.ptr(part_cnt), N, H,
+        _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_fwd")
+    return out, cnt
+
+
+def _run_backward_src(A, B, G, ea_sorted_t, We, csr_t: CSR, graph: MPGraph, gB):
+    """Fills gB (a [Ns, H] view, unit feature stride) and returns gWe."""
+    lib = _lib.load()
+    H = A.size(1)
+    Fe = ea_sorted_t.size(1)
+    dev, dtype = A.device, A.dtype
+    gWe = torch.empty((H, Fe), dtype=dtype, device=dev)
+    part = graph.scratch("part_gB", (csr_t.n_parts, H), torch.float32, dev) if csr_t.n_parts > 0 else None
+    scratch = graph.scratch("gwe", (lib.mpnn_bwd_scratch_floats(H, Fe),), torch.float32, dev)
+    _lib.check(lib.mpnn_aggregate_bwd_src(
+        _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(G), G.stride(0), _lib.ptr(ea_sorted_t), Fe,
+        _lib.ptr(We), _lib.ptr(csr_t.col), _lib.ptr(csr_t.items), csr_t.n_items, _lib.ptr(csr_t.split),
+        csr_t.n_split, csr_t.n_parts, _lib.ptr(gB), gB.stride(0), _lib.ptr(gWe), _lib.ptr(part), _lib.ptr(scratch),
+        csr_t.num_rows, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_bwd_src")
+    return gWe
+
+
+def _prepare(A, B, edge_attr, We, graph: MPGraph):
+    H = A.size(1)
+    _check_features("A", A, graph.num_dst)
+    _check_features("B", B, graph.num_src, H)
+    if We.dim() != 2 or We.size(0) != H or We.size(1) != edge_attr.size(1):
+        raise ValueError(f"We must have shape [{H}, {edge_attr.size(1)}], got {tuple(We.shape)}")
+    if B.dtype != A.dtype or We.dtype != A.dtype:
+        raise TypeError(f"A, B, We must share a dtype, got {A.dtype}, {B.dtype}, {We.dtype}")
+    if edge_attr.requires_grad:
+        raise NotImplementedError("gradient with respect to edge_attr is not implemented by the HIP engine")
+    return graph.sorted_edge_attr(edge_attr, A.dtype)
+
+
+class _AggregateFused(torch.autograd.Function):
+    """out = aggregate(AB[:, :H], AB[:, H:], ...) for a fused [N, 2H] projection (models/layers.py:104-105)."""
+
+    @staticmethod
+    def forward(ctx, AB, edge_attr, We, graph):
+        H = AB.size(1) // 2
+        A, B = AB[:, :H], AB[:, H:]
+        ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
+        We_c = We.contiguous()
+        want = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
+        out, cnt = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
+        if want:
+            ctx.save_for_backward(AB, We_c, cnt, ea_t)
+            ctx.graph = graph
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        AB, We, cnt, ea_t = ctx.saved_tensors
+        graph = ctx.graph
+        H = AB.size(1) // 2
+        g = g.contiguous()
+        gAB = torch.empty_like(AB)
+        torch.mul(g, cnt, out=gAB[:, :H])  # d out / d A: every edge of row n sees A[n]
+        gWe = _run_backward_src(AB[:, :H], AB[:, H:], g, ea_t, We, graph.by_src, graph, gAB[:, H:])
+        return gAB, None, gWe, None
+
+
+class _Aggregate(torch.autograd.Function):
+    """Separate destination table A [Nd, H] and source table B [Ns, H] (partitioned graphs)."""
+
+    @staticmethod
+    def forward(ctx, A, B, edge_attr, We, graph):
+        ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
+        We_c = We.contiguous()
+        want = any(ctx.needs_input_grad[i] for i in (0, 1, 3))
+        out, cnt = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
+        if want:
+            ctx.save_for_backward(A, B, We_c, cnt, ea_t)
+            ctx.graph = graph
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B, We, cnt, ea_t = ctx.saved_tensors
+        graph = ctx.graph
+        g = g.contiguous()
+        gA = (g * cnt).to(A.dtype)
+        gB = torch.empty((graph.num_src, A.size(1)), dtype=A.dtype, device=A.device)
+        gWe = _run_backward_src(A, B, g, ea_t, We, graph.by_src, graph, gB)
+        return gA, gB, None, gWe, None
+
+
+@torch.compiler.disable
+def aggregate_fused(AB: torch.Tensor, edge_attr: torch.Tensor, We: torch.Tensor, graph: MPGraph) -> torch.Tensor:
+    """sum_{e: dst(e)=n} relu((AB[n,:H] + AB[src(e),H:]) + We @ edge_attr[e])  ->  [N, H]."""
+    if AB.dim() != 2 or AB.size(1) % 2 != 0:
+        raise ValueError(f"AB must have shape [N, 2H], got {tuple(AB.shape)}")
+    if not AB.is_contiguous():
+        AB = AB.contiguous()
+    return _AggregateFused.apply(AB, edge_attr, We, graph)
+
+
+@torch.compiler.disable
+def aggregate(A: torch.Tensor, B: torch.Tensor, edge_attr: torch.Tensor, We: torch.Tensor,
+              graph: MPGraph) -> torch.Tensor:
+    """sum_{e: dst(e)=n} relu((A[n] + B[src(e)]) + We @ edge_attr[e])  ->  [num_dst, H]."""
+    if A.stride(-1) != 1:
+        A = A.contiguous()
+    if B.stride(-1) != 1:
+        B = B.contiguous()
+    return _Aggregate.apply(A, B, edge_attr, We, graph)
+
+
+# ----------------------------------------------------------------------------------------
+# segment mean (global_mean_pool)
+# ----------------------------------------------------------------------------------------
+class _SegmentMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, csr: CSR):
+        lib = _lib.load()
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        H = x.size(1)
+        out = torch.empty((csr.num_rows, H), dtype=x.dtype, device=x.device)
+        _lib.check(lib.mpnn_segment_mean_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
+                                             _lib.ptr(out), out.stride(0), csr.num_rows, H,
+                                             _lib.dtype_code(x.dtype), _lib.stream_handle(x.device)),
+                   "mpnn_segment_mean_fwd")
+        ctx.csr = csr
+        ctx.n = x.size(0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        csr = ctx.csr
+        g = g.contiguous()
+        H = g.size(1)
+        gx = torch.empty((ctx.n, H), dtype=g.dtype, device=g.device)
+        _lib.check(lib.mpnn_segment_mean_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
+                                             _lib.ptr(gx), gx.stride(0), csr.num_rows, H,
+                                             _lib.dtype_code(g.dtype), _lib.stream_handle(g.device)),
+                   "mpnn_segment_mean_bwd")
+        return gx, None
+
+
+_POOL_CACHE = {}
+
+
+@torch.compiler.disable
+def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: int | None = None) -> torch.Tensor:
+    """Per-graph mean of node rows; same contract as PyG's global_mean_pool (models/mpnn.py:54,150)."""
+    _lib.require_device(x, "x")
+    if batch is None:
+        return x.mean(dim=0, keepdim=True)
+    if batch.dtype != torch.int64 or batch.dim() != 1 or batch.numel() != x.size(0):
+        raise ValueError("batch must be an int64 vector with one entry per node")
+    key = (batch.data_ptr(), batch._version, batch.numel(), str(batch.device), size)
+    hit = _POOL_CACHE.get(key)
+    if hit is None:
+        if size is None:
+            size = int(batch.max().item()) + 1 if batch.numel() > 0 else 0  # host read, as in the reference
+        nodes = torch.arange(batch.numel(), dtype=torch.int64, device=batch.device)
+        csr = _build_csr(batch.contiguous(), nodes, size, batch.numel(), CHUNK, MAX_PARTS)
+        _POOL_CACHE.clear()  # one entry: mini-batch loops bring a new batch vector every step
+        _POOL_CACHE[key] = (batch, csr)
+    else:
+        csr = hit[1]
+    return _SegmentMean.apply(x, csr)

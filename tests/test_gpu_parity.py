@@ -1,0 +1,253 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (fp32): rel 1e-5 with an absolute floor of 1e-5 * max|expected| (outputs pass through a
+bias-free relu, so many entries are ~0).  bf16: rel 2e-2 with the same kind of floor.
+Integer structures (CSR, transpose, degrees, work items) must match bit for bit.
+"""
+import pytest
+import torch
+
+from conftest import assert_close, load_golden
+from oracle import reference_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL32 = 1e-5
+RTOL16 = 2e-2
+LAYER_CASES = ["layer_tiny", "layer_empty", "layer_qm9", "layer_modelnet", "layer_hub", "layer_odd"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _graph(g, dev):
+    from mpnn_amd.graph import MPGraph
+    return MPGraph(g["edge_index"].to(dev), int(g["num_nodes"]))
+
+
+# --------------------------------------------------------------------------- integer structures
+@pytest.mark.parametrize("case", LAYER_CASES)
+def test_csr_bit_exact_golden(case, dev):
+    g = load_golden(case)
+    graph = _graph(g, dev)
+    for name, got in (("rowptr", graph.by_dst.rowptr), ("col", graph.by_dst.col), ("eid", graph.by_dst.eid),
+                      ("rowptr_t", graph.by_src.rowptr), ("col_t", graph.by_src.col), ("eid_t", graph.by_src.eid),
+                      ("deg_in", graph.by_dst.degree()), ("deg_out", graph.by_src.degree())):
+        assert torch.equal(got.cpu(), g["csr_" + name]), f"{case}: {name} differs"
+    items = graph.by_dst.items[:graph.by_dst.n_items].cpu()
+    split = graph.by_dst.split[:graph.by_dst.n_split].cpu()
+    assert torch.equal(items, g["items"].reshape(-1, 4)), f"{case}: work items differ"
+    assert torch.equal(split, g["split"].reshape(-1, 4)), f"{case}: split rows differ"
+    assert graph.by_dst.n_parts == int(g["n_parts"])
+
+
+def test_csr_bit_exact_random_large(dev):
+    gen = torch.Generator().manual_seed(11)
+    n, e = 5000, 200_000
+    # skewed destinations so that some rows are split into several pieces
+    dst = (torch.rand(e, generator=gen) ** 4 * n).long().clamp_(max=n - 1)
+    src = torch.randint(0, n, (e,), generator=gen)
+    ei = torch.stack([src, dst])
+    want = O.csr_build(ei, n)
+    graph = _graph({"edge_index": ei, "num_nodes": n}, dev)
+    assert torch.equal(graph.by_dst.rowptr.cpu(), want["rowptr"])
+    assert torch.equal(graph.by_dst.col.cpu(), want["col"])
+    assert torch.equal(graph.by_dst.eid.cpu(), want["eid"])
+    assert torch.equal(graph.by_src.rowptr.cpu(), want["rowptr_t"])
+    assert torch.equal(graph.by_src.col.cpu(), want["col_t"])
+    assert torch.equal(graph.by_src.eid.cpu(), want["eid_t"])
+    items, split, parts = O.work_items(want["rowptr"], 64, 256)
+    assert torch.equal(graph.by_dst.items[:graph.by_dst.n_items].cpu(), items)
+    assert torch.equal(graph.by_dst.split[:graph.by_dst.n_split].cpu(), split)
+    assert graph.by_dst.n_parts == parts and parts > 0
+
+
+def test_out_of_range_edge_raises(dev):
+    from mpnn_amd.graph import MPGraph
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]], dtype=torch.int64, device=dev)
+    with pytest.raises(IndexError):
+        MPGraph(ei, 3)
+
+
+# --------------------------------------------------------------------------- aggregate operator
+def _aggregate_case(dev, n, e, H, Fe, seed, skew=False, dtype=torch.float32):
+    from mpnn_amd.graph import MPGraph
+    from mpnn_amd.ops import aggregate_fused
+    gen = torch.Generator().manual_seed(seed)
+    if skew:
+        dst = (torch.rand(e, generator=gen) ** 6 * n).long().clamp_(max=n - 1)
+    else:
+        dst = torch.randint(0, n, (e,), generator=gen)
+    src = torch.randint(0, n, (e,), generator=gen)
+    ei = torch.stack([src, dst])
+    ab = torch.randn(n, 2 * H, generator=gen)
+    ea = torch.rand(e, Fe, generator=gen)
+    we = torch.randn(H, Fe, generator=gen) * 0.5
+    r = torch.randn(n, H, generator=gen)
+    if dtype != torch.float32:
+        ab, ea, we = (t.to(dtype).float() for t in (ab, ea, we))  # oracle sees the rounded inputs
+
+    ab_c = ab.clone().requires_grad_(True)
+    we_c = we.clone().requires_grad_(True)
+    want = O.aggregate_sum_form(ab_c[:, :H], ab_c[:, H:], ea, we_c, ei)
+    (want * r).sum().backward()
+
+    graph = MPGraph(ei.to(dev), n)
+    ab_g = ab.to(dev, dtype).requires_grad_(True)
+    we_g = we.to(dev, dtype).requires_grad_(True)
+    got = aggregate_fused(ab_g, ea.to(dev, dtype), we_g, graph)
+    (got.float() * r.to(dev)).sum().backward()
+    return (got, ab_g.grad, we_g.grad), (want, ab_c.grad, we_c.grad), graph
+
+
+@pytest.mark.parametrize("n,e,H,Fe,skew", [
+    (300, 3000, 64, 4, False),     # QM9/Flickr layer shape
+    (300, 6000, 128, 4, True),     # hidden 128, skewed: split rows in both CSRs
+    (257, 2000, 64, 1, False),     # ModelNet edge width
+    (100, 900, 8, 4, False),       # 2 lanes per row
+    (100, 900, 20, 3, False),      # partial last lane group, generic edge width
+    (64, 500, 7, 2, False),        # scalar path (H % 4 != 0)
+    (50, 400, 320, 4, False),      # two column tiles
+])
+def test_aggregate_fwd_bwd_fp32(n, e, H, Fe, skew, dev):
+    got, want, graph = _aggregate_case(dev, n, e, H, Fe, seed=H + Fe, skew=skew)
+    if skew:
+        assert graph.by_dst.n_parts > 0
+    assert_close(got[0], want[0], RTOL32, what="aggregate out")
+    assert_close(got[1], want[1], RTOL32, what="grad AB")
+    assert_close(got[2], want[2], RTOL32, what="grad We")
+
+
+@pytest.mark.parametrize("n,e,H,Fe", [(300, 3000, 64, 4), (200, 4000, 128, 4), (100, 700, 24, 2)])
+def test_aggregate_fwd_bwd_bf16(n, e, H, Fe, dev):
+    got, want, _ = _aggregate_case(dev, n, e, H, Fe, seed=3, dtype=torch.bfloat16)
+    assert_close(got[0].float(), want[0], RTOL16, what="aggregate out (bf16)")
+    assert_close(got[1].float(), want[1], RTOL16, what="grad AB (bf16)")
+    assert_close(got[2].float(), want[2], RTOL16, what="grad We (bf16)")
+
+
+def test_aggregate_deterministic(dev):
+    a, _, _ = _aggregate_case(dev, 400, 20000, 64, 4, seed=5, skew=True)
+    b, _, _ = _aggregate_case(dev, 400, 20000, 64, 4, seed=5, skew=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), "two runs on the same input differ bitwise"
+
+
+def test_aggregate_separate_tables(dev):
+    """A [Nd,H] and B [Ns,H] given separately, Nd != Ns (a rank-local piece of a partitioned graph)."""
+    from mpnn_amd.graph import MPGraph
+    from mpnn_amd.ops import aggregate
+    gen = torch.Generator().manual_seed(21)
+    nd, ns, e, H, Fe = 70, 190, 1500, 64, 4
+    ei = torch.stack([torch.randint(0, ns, (e,), generator=gen), torch.randint(0, nd, (e,), generator=gen)])
+    a = torch.randn(nd, H, generator=gen)
+    b = torch.randn(ns, H, generator=gen)
+    ea = torch.rand(e, Fe, generator=gen)
+    we = torch.randn(H, Fe, generator=gen)
+    r = torch.randn(nd, H, generator=gen)
+    ac, bc, wc = (t.clone().requires_grad_(True) for t in (a, b, we))
+    msg = torch.relu((ac[ei[1]] + bc[ei[0]]) + ea @ wc.t())
+    want = torch.zeros(nd, H).index_add_(0, ei[1], msg)
+    (want * r).sum().backward()
+    graph = MPGraph(ei.to(dev), nd, ns)
+    ag, bg, wg = (t.to(dev).requires_grad_(True) for t in (a, b, we))
+    got = aggregate(ag, bg, ea.to(dev), wg, graph)
+    (got * r.to(dev)).sum().backward()
+    assert_close(got, want, RTOL32, what="out")
+    assert_close(ag.grad, ac.grad, RTOL32, what="gA")
+    assert_close(bg.grad, bc.grad, RTOL32, what="gB")
+    assert_close(wg.grad, wc.grad, RTOL32, what="gWe")
+
+
+# --------------------------------------------------------------------------- layers against golden vectors
+@pytest.mark.parametrize("case", LAYER_CASES)
+@pytest.mark.parametrize("mode", ["cat", "sum"])
+def test_layer_golden(case, mode, dev):
+    from mpnn_amd import MPNNLayerCat, MPNNLayerSum
+    g = load_golden(case)
+    n = int(g["num_nodes"])
+    F_in, Fe = g["x"].size(1), g["edge_attr"].size(1)
+    H = g["r"].size(1)
+    if mode == "cat":
+        layer = MPNNLayerCat(F_in, Fe, H)
+        names = {"linear": "w_cat_linear", "linear_out": "w_cat_linear_out"}
+    else:
+        layer = MPNNLayerSum(F_in, Fe, H)
+        names = {"fused_linear": "w_sum_fused_linear", "linear_3": "w_sum_linear_3", "linear_out": "w_sum_linear_out"}
+    with torch.no_grad():
+        for attr, key in names.items():
+            getattr(layer, attr).weight.copy_(g[key])
+    layer = layer.to(dev)
+    x = g["x"].to(dev).requires_grad_(True)
+    out = layer(x, g["edge_index"].to(dev), g["edge_attr"].to(dev))
+    assert out.shape == (n, H)
+    (out * g["r"].to(dev)).sum().backward()
+    assert_close(out, g[f"{mode}_out"], RTOL32, what=f"{case}/{mode} out")
+    assert_close(x.grad, g[f"{mode}_gx"], RTOL32, what=f"{case}/{mode} grad x")
+    for attr in names:
+        assert_close(getattr(layer, attr).weight.grad, g[f"{mode}_g_{attr}"], RTOL32,
+                     what=f"{case}/{mode} grad {attr}")
+    # float64 recomputation of the oracle bounds how much of the budget is rounding in the oracle itself
+    assert_close(out, g[f"{mode}_out64"], 4 * RTOL32, what=f"{case}/{mode} out vs float64")
+
+
+# --------------------------------------------------------------------------- pooling and models
+def test_global_mean_pool_golden(dev):
+    from mpnn_amd import global_mean_pool
+    g = load_golden("pool")
+    x = g["x"].to(dev).requires_grad_(True)
+    out = global_mean_pool(x, g["batch_sorted"].to(dev), 6)
+    assert_close(out, g["out_sorted"], RTOL32, what="pool sorted")
+    out.sum().backward()
+    cnt = torch.bincount(g["batch_sorted"], minlength=6).clamp(min=1).float()
+    assert_close(x.grad, (1.0 / cnt)[g["batch_sorted"]].view(-1, 1).expand(-1, 20), RTOL32, what="pool grad")
+    out2 = global_mean_pool(g["x"].to(dev), g["batch_sorted"][g["perm"]].to(dev), 6)
+    assert_close(out2, g["out_unsorted"], RTOL32, what="pool unsorted")
+
+
+@pytest.mark.parametrize("mode", ["cat", "sum"])
+def test_model_qm9_golden_with_adam_step(mode, dev):
+    from mpnn_amd import MPNN, MPNN_QM9
+    g = load_golden("model_qm9")
+    model = MPNN_QM9(11, 4, 64, 19, num_layers=2, mode=mode)
+    state = {k[len(mode) + 7:]: v for k, v in g.items() if k.startswith(f"{mode}.param.")}
+    model.load_state_dict(state, strict=True)   # same state_dict keys as the reference
+    model = model.to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.003)
+    x, ei, batch, ea = (g[k].to(dev) for k in ("x", "edge_index", "batch", "edge_attr"))
+    logits = model(x, ei, batch, ea)           # reference argument order: batch before edge_attr
+    loss = torch.nn.functional.mse_loss(logits, g["y"].to(dev))
+    loss.backward()
+    assert_close(logits, g[f"{mode}.logits"], RTOL32, what="logits")
+    for k, p in model.named_parameters():
+        assert_close(p.grad, g[f"{mode}.grad.{k}"], RTOL32, atol_scale=2.0, what=f"grad {k}")
+    opt.step()
+    for k, p in model.named_parameters():
+        assert_close(p, g[f"{mode}.after_adam.{k}"], 1e-4, what=f"after Adam {k}")
+
+    node_model = MPNN(11, 64, 19, num_layers=2, mode=mode)
+    node_model.load_state_dict(state, strict=True)
+    node_logits = node_model.to(dev)(x, ei, ea)
+    assert_close(node_logits, g[f"{mode}.node_logits"], RTOL32, what="node logits")
+
+
+def test_graph_cache_reuses_and_invalidates(dev):
+    from mpnn_amd.graph import graph_for, clear_cache
+    clear_cache()
+    ei = torch.tensor([[0, 1, 2], [1, 2, 0]], dtype=torch.int64, device=dev)
+    g1 = graph_for(ei, 3)
+    assert graph_for(ei, 3) is g1
+    ei[0, 0] = 2                      # in-place edit bumps the version counter
+    g2 = graph_for(ei, 3)
+    assert g2 is not g1
+    assert g2.by_dst.col.cpu().tolist() == [2, 2, 1]
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    from mpnn_amd import MPNNLayerSum
+    from mpnn_amd._lib import MpnnError
+    layer = MPNNLayerSum(4, 4, 8)
+    with pytest.raises(MpnnError):
+        layer(torch.zeros(3, 4), torch.zeros((2, 2), dtype=torch.int64), torch.zeros(2, 4))
