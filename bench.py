@@ -1,0 +1,243 @@
+"""Benchmark of the MPNN layer hot path: edges/sec for one layer forward+backward.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload powerlaw|flickr|modelnet|qm9]
+                  [--mode sum|cat] [--dtype f32|bf16] [--no-cpu-baseline]
+
+A step is one full forward + backward of one MPNN layer (node GEMMs, fused gather/message/
+aggregate pass, update GEMM, and every gradient: x, all weights) on a synthetic graph whose
+tensors are already in HBM.  With N > 1 the graph is partitioned by destination range and the
+step includes the halo all-gather, the reduce-scatter of the halo gradient and the weight
+gradient all-reduce (one process per GPU, launched by torch.distributed.run).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant HIP kernel (timed with events on
+the stream it runs on, inside the timed region); `cpu_baseline` is the CPU oracle timed on the
+host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+WORKLOADS = {
+    # name: (generator kwargs, in_features, hidden, edge_features)
+    "powerlaw": dict(F=128, H=128, Fe=4, desc="S3DIS-scale power-law graph, 4,000,000 nodes, 100,000,000 edges"),
+    "flickr": dict(F=500, H=64, Fe=4, desc="Flickr-shaped graph, 89,250 nodes, 899,756 edges, layer 1 (500->64)"),
+    "modelnet": dict(F=3, H=64, Fe=1, desc="ModelNet-shaped batch, 32 clouds x 1024 points, k-NN k=20"),
+    "qm9": dict(F=11, H=64, Fe=4, desc="QM9-shaped batch of 1024 molecules (~18 atoms, ~38 directed bonds)"),
+}
+
+
+def make_data(name, device, scale=1.0, seed=0):
+    from mpnn_amd import synth
+    if name == "powerlaw":
+        n = max(int(4_000_000 * scale), 1000)
+        e = max(int(100_000_000 * scale), 10_000)
+        return synth.powerlaw(device, seed, n, e, 128, 4)
+    if name == "flickr":
+        return synth.flickr(device, seed, max(int(89_250 * scale), 100), max(int(899_756 * scale) // 2 * 2, 200))
+    if name == "modelnet":
+        return synth.modelnet(device, seed, max(int(32 * scale), 1))
+    if name == "qm9":
+        return synth.qm9(device, seed, max(int(1024 * scale), 1))
+    raise ValueError(name)
+
+
+def layer_bytes_model(n, e, h, fe, s):
+    """Three-pass algorithmic traffic of one layer fwd+bwd (gather, relu-mask recompute, no atomics):
+    E*(16 + 4*H*s + 3*Fe*s) + N*(12 + 7*H*s)."""
+    return e * (16 + 4 * h * s + 3 * fe * s) + n * (12 + 7 * h * s)
+
+
+def kernel_bytes(kind, n_rows, e, h, fe, s):
+    """Compulsory bytes of one launch of this build's two edge kernels."""
+    if kind == "aggregate_fwd":   # col, B[src] row, edge_attr | item record, A row, out row, cnt row (float)
+        return e * (4 + h * s + fe * s) + n_rows * (16 + 2 * h * s + 4 * h)
+    if kind == "aggregate_bwd_src":  # col_t, A[dst] row, G[dst] row, edge_attr | item record, B row, gB row
+        return e * (4 + 2 * h * s + fe * s) + n_rows * (16 + 2 * h * s)
+    raise ValueError(kind)
+
+
+def cpu_baseline(name, mode, target_seconds=20.0):
+    """CPU oracle (plain torch ops, the arithmetic the reference runs through PyG) on a bounded sample."""
+    from oracle import reference_oracle as O
+    cfg = WORKLOADS[name]
+    scale = {"powerlaw": 0.02, "flickr": 1.0, "modelnet": 1.0, "qm9": 1.0}[name]
+    d = make_data(name, "cpu", scale=scale, seed=0)
+    x, ei, ea = d["x"].float(), d["edge_index"], d["edge_attr"].float()
+    F_in, H, Fe = x.size(1), cfg["H"], ea.size(1)
+    gen = torch.Generator().manual_seed(1)
+    w_out = (torch.rand(H, H + F_in, generator=gen) - 0.5).requires_grad_(True)
+    if mode == "cat":
+        ws = [(torch.rand(H, 2 * F_in + Fe, generator=gen) - 0.5).requires_grad_(True), w_out]
+        fn = lambda xx: O.layer_cat(xx, ei, ea, ws[0], ws[1])
+    else:
+        ws = [(torch.rand(2 * H, F_in, generator=gen) - 0.5).requires_grad_(True),
+              (torch.rand(H, Fe, generator=gen) - 0.5).requires_grad_(True), w_out]
+        fn = lambda xx: O.layer_sum(xx, ei, ea, ws[0], ws[1], ws[2])
+    x = x.requires_grad_(True)
+    r = torch.randn(x.size(0), H, generator=gen)
+
+    def step():
+        out = fn(x)
+        torch.autograd.grad((out * r).sum(), [x] + ws)
+
+    step()  # warm-up
+    t0 = time.perf_counter()
+    step()
+    one = time.perf_counter() - t0
+    reps = max(1, min(10, int(target_seconds / max(one, 1e-3)) - 1))
+    times = [one]
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {
+        "value": ei.size(1) / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"{name} generator at scale {scale} (N={x.size(0)}, E={ei.size(1)}), MPNNLayer{mode.capitalize()} "
+                  f"fwd+bwd with plain torch CPU ops, median of {len(times)} runs after 1 warm-up",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="powerlaw", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="sum", choices=["sum", "cat"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mpnn_amd import MPNNLayerCat, MPNNLayerSum, ops
+    from mpnn_amd.partition import PartitionedGraph, allreduce_gradients, partitioned_layer
+
+    cfg = WORKLOADS[args.workload]
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    s = 4 if args.dtype == "f32" else 2
+
+    d = make_data(args.workload, dev, scale=args.scale, seed=0)
+    n_total, e_total = d["num_nodes"], d["edge_index"].size(1)
+    F_in, H, Fe = d["x"].size(1), cfg["H"], d["edge_attr"].size(1)
+    torch.manual_seed(0)
+    layer = (MPNNLayerSum if args.mode == "sum" else MPNNLayerCat)(F_in, Fe, H).to(dev, dtype)
+
+    if world == 1:
+        x = d["x"].to(dtype).requires_grad_(True)
+        ei, ea = d["edge_index"], d["edge_attr"].to(dtype)
+        from mpnn_amd.graph import graph_for
+        graph_for(ei, n_total)            # built once and cached, outside the timed region (static graph)
+        n_rows_fwd, n_rows_bwd, e_local = n_total, n_total, e_total
+        forward = lambda: layer(x, ei, ea)
+    else:
+        pg = PartitionedGraph(d["edge_index"], n_total, rank, world)
+        x = pg.local_rows(d["x"]).to(dtype).clone().requires_grad_(True)
+        ea = pg.local_edges(d["edge_attr"]).to(dtype).clone()
+        n_rows_fwd, n_rows_bwd, e_local = pg.n_local, world * pg.n_pad, pg.edge_ids.numel()
+        forward = lambda: partitioned_layer(layer, x, pg, ea)
+    del d
+    torch.cuda.empty_cache()
+    gen = torch.Generator(device=dev).manual_seed(2)
+    r = torch.randn(x.size(0), H, generator=gen, device=dev).to(dtype)
+
+    def step():
+        for p in layer.parameters():
+            p.grad = None
+        x.grad = None
+        out = forward()
+        out.backward(r)          # dense upstream gradient, as a following layer would supply
+        if world > 1:
+            allreduce_gradients(layer)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.EVENT_SINK = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    events, ops.EVENT_SINK = ops.EVENT_SINK, None
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel time from the events recorded on the launch stream during the timed steps
+    kt = {}
+    for name, a, b in events:
+        kt.setdefault(name, []).append(a.elapsed_time(b) * 1e-3)
+    kavg = {k: sum(v) / len(v) for k, v in kt.items()}
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        rows = {"aggregate_fwd": n_rows_fwd, "aggregate_bwd_src": n_rows_bwd}
+        per_kernel = {}
+        for k, tk in kavg.items():
+            b = kernel_bytes(k, rows[k], e_local, H, Fe, s)
+            per_kernel[k] = {"avg_ms": tk * 1e3, "algorithmic_bytes": b, "GBps": b / tk / 1e9}
+        dom = max(kavg, key=kavg.get)
+        mp_time = sum(kavg.values())
+        model_bytes = layer_bytes_model(n_rows_fwd, e_local, H, Fe, s)
+        result = {
+            "metric": "edges_per_sec_mpnn_layer_fwd_bwd",
+            "value": e_total / (elapsed / args.steps),
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['desc']}" + (f" (scale {args.scale})" if args.scale != 1 else ""),
+                       "layer": f"MPNNLayer{args.mode.capitalize()}", "num_nodes": n_total, "num_edges": e_total,
+                       "in_features": F_in, "hidden": H, "edge_features": Fe,
+                       "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world} + halo all-gather"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None},
+            "kernels": per_kernel,
+            "message_passing_only": {
+                "ms": mp_time * 1e3, "edges_per_sec": e_local / mp_time,
+                "three_pass_model_bytes": model_bytes,
+                "three_pass_model_frac_of_hbm_peak": model_bytes / mp_time / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.workload, args.mode)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,29 @@ from . import _lib
 from .graph import CSR, MPGraph, _build_csr, CHUNK, MAX_PARTS
 
 
+# Optional timing hook: when set to a list, every library call of the two edge passes appends
+# (name, start_event, end_event) recorded on the stream the kernels run on.
+EVENT_SINK = None
+
+
+class _Timed:
+    def __init__(self, name, device):
+        self.name, self.device = name, device
+
+    def __enter__(self):
+        if EVENT_SINK is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t1 = torch.cuda.Event(enable_timing=True)
+            self.t0.record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, *exc):
+        if EVENT_SINK is not None:
+            self.t1.record(torch.cuda.current_stream(self.device))
+            EVENT_SINK.append((self.name, self.t0, self.t1))
+        return False
+
+
 def _check_features(name, t, rows, H=None):
     _lib.require_device(t, name)
     if t.dim() != 2 or t.size(0) != rows or (H is not None and t.size(1) != H):
@@ -32,11 +55,12 @@ def _run_forward(A, B, ea_sorted, We, csr: CSR, graph: MPGraph, want_cnt: bool):
         part_out = graph.scratch("part_out", (csr.n_parts, H), torch.float32, dev)
         if want_cnt:
             part_cnt = graph.scratch("part_cnt", (csr.n_parts, H), torch.float32, dev)
-    _lib.check(lib.mpnn_aggregate_fwd(
-        _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(ea_sorted), ea_sorted.size(1), _lib.ptr(We),
-        _lib.ptr(csr.col), _lib.ptr(csr.items), csr.n_items, _lib.ptr(csr.split), csr.n_split, csr.n_parts,
-        _lib.ptr(out), out.stride(0), _lib.ptr(cnt), _lib.ptr(part_out), _lib.ptr(part_cnt), N, H,
-        _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_fwd")
+    with _Timed("aggregate_fwd", dev):
+        _lib.check(lib.mpnn_aggregate_fwd(
+            _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(ea_sorted), ea_sorted.size(1), _lib.ptr(We),
+            _lib.ptr(csr.col), _lib.ptr(csr.items), csr.n_items, _lib.ptr(csr.split), csr.n_split, csr.n_parts,
+            _lib.ptr(out), out.stride(0), _lib.ptr(cnt), _lib.ptr(part_out), _lib.ptr(part_cnt), N, H,
+            _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_fwd")
     return out, cnt
 
 
@@ -49,11 +73,13 @@ def _run_backward_src(A, B, G, ea_sorted_t, We, csr_t: CSR, graph: MPGraph, gB):
     gWe = torch.empty((H, Fe), dtype=dtype, device=dev)
     part = graph.scratch("part_gB", (csr_t.n_parts, H), torch.float32, dev) if csr_t.n_parts > 0 else None
     scratch = graph.scratch("gwe", (lib.mpnn_bwd_scratch_floats(H, Fe),), torch.float32, dev)
-    _lib.check(lib.mpnn_aggregate_bwd_src(
-        _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(G), G.stride(0), _lib.ptr(ea_sorted_t), Fe,
-        _lib.ptr(We), _lib.ptr(csr_t.col), _lib.ptr(csr_t.items), csr_t.n_items, _lib.ptr(csr_t.split),
-        csr_t.n_split, csr_t.n_parts, _lib.ptr(gB), gB.stride(0), _lib.ptr(gWe), _lib.ptr(part), _lib.ptr(scratch),
-        csr_t.num_rows, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_bwd_src")
+    with _Timed("aggregate_bwd_src", dev):
+        _lib.check(lib.mpnn_aggregate_bwd_src(
+            _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(G), G.stride(0), _lib.ptr(ea_sorted_t), Fe,
+            _lib.ptr(We), _lib.ptr(csr_t.col), _lib.ptr(csr_t.items), csr_t.n_items, _lib.ptr(csr_t.split),
+            csr_t.n_split, csr_t.n_parts, _lib.ptr(gB), gB.stride(0), _lib.ptr(gWe), _lib.ptr(part),
+            _lib.ptr(scratch), csr_t.num_rows, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)),
+            "mpnn_aggregate_bwd_src")
     return gWe
 
 
