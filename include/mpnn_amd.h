@@ -162,6 +162,49 @@ int32_t mpnn_aggregate_bwd_src(const void* A, int64_t ldA, const void* B, int64_
                                int32_t dtype, mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * EGNN coordinate update fused into the aggregation pass.
+ *
+ * No counterpart in the reference (its models/layers.py holds only MPNNLayerCat and
+ * MPNNLayerSum); the operator extends the message pass of models/layers.py:128 by
+ *     m_e    = relu((A[dst] + B[src]) + We @ edge_attr[e])
+ *     out_n  = sum_{e -> n} m_e
+ *     pos'_n = pos_n + sum_{e -> n} (pos_n - pos_src(e)) * (w_pos . m_e)
+ * Coordinates and their gradients are float [*, 3] whatever the feature dtype.
+ * Requires the vector path: H % 4 == 0 (f32) / H % 8 == 0 (bf16), H <= 256 / 512,
+ * 16-byte aligned feature matrices.  part_small is float [n_parts, 4] scratch.
+ *
+ * Backward, with G = d loss / d out and gpos_out = d loss / d pos':
+ *   mpnn_egnn_bwd_dst (destination-sorted CSR):  gA, S[n] = sum_{e -> n} (w_pos . m_e), g_wpos
+ *   mpnn_egnn_bwd_src (source-sorted transpose): gB, gWe, gpos_src[s] = -sum_{e from s} (w_pos . m_e) gpos_out[dst]
+ *   d loss / d pos = gpos_out * (1 + S) + gpos_src     (elementwise, left to the caller)
+ * scratch: float, at least mpnn_bwd_scratch_floats(H, Fe) elements.
+ * ------------------------------------------------------------------------- */
+int32_t mpnn_egnn_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB,
+                      const void* ea_sorted, int32_t Fe, const void* We, const void* w_pos,
+                      const float* pos_dst, const float* pos_src, const int32_t* col,
+                      const int32_t* items, int64_t n_items, const int32_t* split,
+                      int64_t n_split, int64_t n_parts, void* out, int64_t ldo,
+                      float* pos_out, float* part_out, float* part_small, int64_t num_nodes,
+                      int32_t H, int32_t dtype, mpnn_stream_t stream);
+int32_t mpnn_egnn_bwd_dst(const void* A, int64_t ldA, const void* B, int64_t ldB,
+                          const void* G, int64_t ldG, const float* gpos_out,
+                          const void* ea_sorted, int32_t Fe, const void* We, const void* w_pos,
+                          const float* pos_dst, const float* pos_src, const int32_t* col,
+                          const int32_t* items, int64_t n_items, const int32_t* split,
+                          int64_t n_split, int64_t n_parts, void* gA, int64_t ldgA, float* S,
+                          void* g_wpos, float* part_gA, float* part_small, float* scratch,
+                          int64_t num_nodes, int32_t H, int32_t dtype, mpnn_stream_t stream);
+int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB,
+                          const void* G, int64_t ldG, const float* gpos_out,
+                          const void* ea_sorted_t, int32_t Fe, const void* We, const void* w_pos,
+                          const float* pos_dst, const float* pos_src, const int32_t* col_t,
+                          const int32_t* items_t, int64_t n_items_t, const int32_t* split_t,
+                          int64_t n_split_t, int64_t n_parts_t, void* gB, int64_t ldgB,
+                          float* gpos_src, void* gWe, float* part_gB, float* part_small,
+                          float* scratch, int64_t num_src_nodes, int32_t H, int32_t dtype,
+                          mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Segment mean over an index list: out[g, :] = (1/max(cnt_g,1)) * sum_{p in seg g} x[col[p], :]
  * and its backward gx[col[p], :] = gout[g, :] / max(cnt_g, 1).
  *

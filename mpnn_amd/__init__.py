@@ -1,8 +1,8 @@
 """MI355X-native message-passing engine behind the KutayTasci/MPNN model API."""
-from .layers import MPNNLayerCat, MPNNLayerSum
+from .layers import EGNNLayer, MPNNLayerCat, MPNNLayerSum
 from .mpnn import MPNN, MPNN_QM9, MPNN_ModelNet
 from .graph import MPGraph, graph_for
-from .ops import aggregate, aggregate_fused, global_mean_pool
+from .ops import aggregate, aggregate_fused, egnn_aggregate, global_mean_pool
 
-__all__ = ["MPNNLayerCat", "MPNNLayerSum", "MPNN", "MPNN_QM9", "MPNN_ModelNet", "MPGraph", "graph_for",
+__all__ = ["EGNNLayer", "egnn_aggregate", "MPNNLayerCat", "MPNNLayerSum", "MPNN", "MPNN_QM9", "MPNN_ModelNet", "MPGraph", "graph_for",
            "aggregate", "aggregate_fused", "global_mean_pool"]

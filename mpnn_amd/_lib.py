@@ -37,6 +37,18 @@ SIGNATURES = {
                                          c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_int32, c_int32, c_void_p]),
+    "mpnn_egnn_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                                c_void_p]),
+    "mpnn_egnn_bwd_dst": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
+    "mpnn_egnn_bwd_src": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_segment_mean_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                         c_int32, c_int32, c_void_p]),
     "mpnn_segment_mean_bwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch.nn import Linear
 
 from .graph import graph_for
-from .ops import aggregate_fused
+from .ops import aggregate_fused, egnn_aggregate
 
 
 def _update(x: torch.Tensor, aggr: torch.Tensor, w_out: torch.Tensor) -> torch.Tensor:
@@ -60,3 +60,28 @@ class MPNNLayerSum(torch.nn.Module):
         ab = self.fused_linear(x)  # xs = ab[:, :H] (target), xt = ab[:, H:] (source)
         aggr = aggregate_fused(ab, edge_attr, self.linear_3.weight, graph)
         return _update(x, aggr, self.linear_out.weight)
+
+
+class EGNNLayer(torch.nn.Module):
+    """MPNNLayerSum plus a coordinate update (no counterpart in the reference).
+
+    h, pos -> relu(linear_out([h | sum_e m_e])),  pos + sum_e (pos_i - pos_j) * coord_linear(m_e)
+    with m_e = relu(xs_i + xt_j + linear_3(edge_attr)) as in models/layers.py:104-110,128 and coord_linear a
+    bias-free Linear(H, 1).  The message sum and the coordinate update share one edge pass.
+    """
+
+    def __init__(self, in_channels, edge_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.edge_channels, self.out_channels = in_channels, edge_channels, out_channels
+        self.fused_linear = Linear(in_channels, out_channels * 2, bias=False)
+        self.linear_3 = Linear(edge_channels, out_channels, bias=False)
+        self.linear_out = Linear(out_channels + in_channels, out_channels, bias=False)
+        self.coord_linear = Linear(out_channels, 1, bias=False)
+
+    def forward(self, x, pos, edge_index, edge_attr):
+        graph = graph_for(edge_index, x.size(0))
+        ab = self.fused_linear(x)
+        h = self.out_channels
+        aggr, pos_out = egnn_aggregate(ab[:, :h], ab[:, h:], edge_attr, self.linear_3.weight, pos.float(),
+                                       self.coord_linear.weight.view(-1), graph)
+        return _update(x, aggr, self.linear_out.weight), pos_out

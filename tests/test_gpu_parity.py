@@ -251,3 +251,71 @@ def test_cpu_tensor_is_rejected_loudly():
     layer = MPNNLayerSum(4, 4, 8)
     with pytest.raises(MpnnError):
         layer(torch.zeros(3, 4), torch.zeros((2, 2), dtype=torch.int64), torch.zeros(2, 4))
+
+
+# --------------------------------------------------------------------------- EGNN coordinate update
+# No reference counterpart: parity is against the build's own oracle of the formula
+# pos_i += sum_j (pos_i - pos_j) * phi_x(m_ij)  (oracle/reference_oracle.py::egnn_layer) -- parity unpinned.
+def test_egnn_golden(dev):
+    from mpnn_amd import egnn_aggregate
+    g = load_golden("egnn")
+    graph = _graph(g, dev)
+    aggr, pos = egnn_aggregate(g["a"].to(dev), g["b"].to(dev), g["edge_attr"].to(dev), g["w_edge"].to(dev),
+                               g["pos"].to(dev), g["w_pos"].to(dev), graph)
+    assert_close(aggr, g["aggr"], RTOL32, what="egnn aggr")
+    assert_close(pos, g["pos_out"], RTOL32, what="egnn pos")
+
+
+@pytest.mark.parametrize("n,e,H,Fe,skew,dtype", [
+    (300, 3000, 64, 4, False, torch.float32),
+    (200, 6000, 128, 1, True, torch.float32),
+    (150, 1500, 8, 3, False, torch.float32),
+    (300, 3000, 64, 4, False, torch.bfloat16),
+])
+def test_egnn_fwd_bwd(n, e, H, Fe, skew, dtype, dev):
+    from mpnn_amd import egnn_aggregate
+    from mpnn_amd.graph import MPGraph
+    gen = torch.Generator().manual_seed(31 + H)
+    dst = ((torch.rand(e, generator=gen) ** 6 * n).long().clamp_(max=n - 1) if skew
+           else torch.randint(0, n, (e,), generator=gen))
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), dst])
+    a, b = torch.randn(n, H, generator=gen), torch.randn(n, H, generator=gen)
+    ea = torch.rand(e, Fe, generator=gen)
+    we = torch.randn(H, Fe, generator=gen) * 0.5
+    wp = torch.randn(H, generator=gen) / H
+    pos = torch.rand(n, 3, generator=gen) * 2 - 1
+    r, rp = torch.randn(n, H, generator=gen), torch.randn(n, 3, generator=gen)
+    if dtype != torch.float32:
+        a, b, ea, we, wp = (t.to(dtype).float() for t in (a, b, ea, we, wp))
+    leaves = [t.clone().requires_grad_(True) for t in (a, b, we, pos, wp)]
+    aggr_w, pos_w = O.egnn_layer(leaves[0], leaves[1], ea, leaves[2], leaves[3], leaves[4], ei)
+    ((aggr_w * r).sum() + (pos_w * rp).sum()).backward()
+
+    graph = MPGraph(ei.to(dev), n)
+    if skew:
+        assert graph.by_dst.n_parts > 0
+    gl = [t.to(dev, dtype if i != 3 else torch.float32).requires_grad_(True) for i, t in enumerate((a, b, we, pos, wp))]
+    aggr_g, pos_g = egnn_aggregate(gl[0], gl[1], ea.to(dev, dtype), gl[2], gl[3], gl[4], graph)
+    ((aggr_g.float() * r.to(dev)).sum() + (pos_g * rp.to(dev)).sum()).backward()
+    rtol = RTOL32 if dtype == torch.float32 else RTOL16
+    assert_close(aggr_g.float(), aggr_w, rtol, what="aggr")
+    assert_close(pos_g, pos_w, rtol, what="pos'")
+    for name, got, want in zip(("gA", "gB", "gWe", "gpos", "gwpos"), gl, leaves):
+        assert_close(got.grad.float(), want.grad, rtol, atol_scale=4.0, what=name)
+
+
+def test_egnn_layer_module(dev):
+    from mpnn_amd import EGNNLayer
+    g = load_golden("layer_modelnet")
+    torch.manual_seed(0)
+    layer = EGNNLayer(3, 1, 64).to(dev)
+    x = g["x"].to(dev)
+    h, pos = layer(x, x, g["edge_index"].to(dev), g["edge_attr"].to(dev))
+    want_aggr, want_pos = O.egnn_layer(*(t.detach().cpu() for t in (
+        layer.fused_linear(x)[:, :64], layer.fused_linear(x)[:, 64:])), g["edge_attr"],
+        layer.linear_3.weight.detach().cpu(), g["x"], layer.coord_linear.weight.detach().cpu().view(-1),
+        g["edge_index"])
+    assert_close(pos, want_pos, RTOL32, what="layer pos'")
+    assert_close(h, O.update(g["x"], want_aggr, layer.linear_out.weight.detach().cpu()), RTOL32, what="layer h")
+    (h.sum() + pos.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
