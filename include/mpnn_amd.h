@@ -205,6 +205,31 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
                           mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Dense fp32 GEMMs of the layer on the matrix cores (exact f32 MFMA).
+ *
+ * Replace the node-level Linear calls of the reference and their autograd backward:
+ *   models/layers.py:104 fused_linear(x); models/layers.py:56 linear(...) after the column split;
+ *   models/layers.py:69,140 relu(linear_out(cat[x, aggr])) as  x W_x^T + aggr W_a^T  without the cat.
+ *
+ * mpnn_gemm_nt_f32:  Y[N,M] = act( X1[N,K1] W1[M,K1]^T + X2[N,K2] W2[M,K2]^T ),  act = relu if `relu` != 0.
+ *   The second term is skipped when K2 == 0.  maskI (optional, same shape as XI): XI is read as
+ *   XI * (maskI > 0) -- the relu backward fused into the operand load.  With a pre-transposed weight the
+ *   same entry point computes input gradients (dX = G W  ==  G (W^T)^T).
+ * mpnn_gemm_tn_f32:  dW[M,K] = (G * (mask > 0))[N,M]^T X[N,K]  (weight gradient; rows are summed in a fixed
+ *   order through `scratch`, float, at least mpnn_gemm_tn_scratch_floats(N, M, K) elements).
+ * All matrices row-major with leading dimensions in elements.
+ * ------------------------------------------------------------------------- */
+int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int64_t ldm1,
+                         const float* W1, int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2,
+                         const float* mask2, int64_t ldm2, const float* W2, int64_t ldw2, int32_t K2,
+                         float* Y, int64_t ldy, int64_t N, int32_t M, int32_t relu,
+                         mpnn_stream_t stream);
+int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K);
+int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm,
+                         const float* X, int64_t ldx, float* dW, int64_t lddw, float* scratch,
+                         int64_t N, int32_t M, int32_t K, mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * Segment mean over an index list: out[g, :] = (1/max(cnt_g,1)) * sum_{p in seg g} x[col[p], :]
  * and its backward gx[col[p], :] = gout[g, :] / max(cnt_g, 1).
  *

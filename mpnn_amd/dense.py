@@ -1,0 +1,128 @@
+"""Dense node-level operators of the layer on the fp32 MFMA kernels of libmpnn_amd.so.
+
+``project``  : AB = x @ W^T                                     (models/layers.py:104, and :56 after the column split)
+``update``   : relu(x @ W_out[:, :F]^T + aggr @ W_out[:, F:]^T)  (models/layers.py:69,140, no cat)
+
+Both carry their own backward (input gradients through the same NT kernel with a transposed weight, weight
+gradients through the TN kernel, the relu mask fused into the operand loads).  float32 on the GPU only;
+bfloat16 models keep the library GEMMs of torch for these plain Linear calls.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+
+_SCRATCH = {}
+
+
+def _scratch(n: int, device) -> torch.Tensor:
+    buf = _SCRATCH.get(device)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(n, dtype=torch.float32, device=device)
+        _SCRATCH[device] = buf
+    return buf
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    return t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()
+
+
+def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False) -> torch.Tensor:
+    """act(x1 @ w1^T [+ x2 @ w2^T]); maskI > 0 selects the entries of xI that are used."""
+    lib = _lib.load()
+    x1, w1 = _rows(x1), _rows(w1)
+    n, k1 = x1.shape
+    m = w1.size(0)
+    y = torch.empty((n, m), dtype=torch.float32, device=x1.device)
+    if x2 is not None:
+        x2, w2 = _rows(x2), _rows(w2)
+    mask1 = _rows(mask1) if mask1 is not None else None
+    mask2 = _rows(mask2) if mask2 is not None else None
+    _lib.check(lib.mpnn_gemm_nt_f32(
+        _lib.ptr(x1), x1.stride(0), _lib.ptr(mask1), mask1.stride(0) if mask1 is not None else 0, _lib.ptr(w1),
+        w1.stride(0), k1,
+        _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(mask2),
+        mask2.stride(0) if mask2 is not None else 0, _lib.ptr(w2), w2.stride(0) if w2 is not None else 0,
+        x2.size(1) if x2 is not None else 0,
+        _lib.ptr(y), y.stride(0), n, m, 1 if relu else 0, _lib.stream_handle(x1.device)), "mpnn_gemm_nt_f32")
+    return y
+
+
+def gemm_tn(g, x, mask=None, out=None) -> torch.Tensor:
+    """(g * (mask > 0))^T @ x  ->  [M, K]; ``out`` may be a column slice of a wider weight gradient."""
+    lib = _lib.load()
+    g, x = _rows(g), _rows(x)
+    n, m = g.shape
+    k = x.size(1)
+    if out is None:
+        out = torch.empty((m, k), dtype=torch.float32, device=g.device)
+    mask = _rows(mask) if mask is not None else None
+    scratch = _scratch(lib.mpnn_gemm_tn_scratch_floats(n, m, k), g.device)
+    _lib.check(lib.mpnn_gemm_tn_f32(
+        _lib.ptr(g), g.stride(0), _lib.ptr(mask), mask.stride(0) if mask is not None else 0, _lib.ptr(x),
+        x.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(scratch), n, m, k, _lib.stream_handle(g.device)),
+        "mpnn_gemm_tn_f32")
+    return out
+
+
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return gemm_nt(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _rows(g)
+        gx = gemm_nt(g, w.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gw = gemm_tn(g, x) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class _Update(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, aggr, w_out):
+        f = x.size(1)
+        y = gemm_nt(x, w_out[:, :f], aggr, w_out[:, f:], relu=True)
+        ctx.save_for_backward(x, aggr, w_out, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, aggr, w_out, y = ctx.saved_tensors
+        f = x.size(1)
+        gy = _rows(gy)
+        gx = ga = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wt = w_out.t().contiguous()          # [F+H, H]: rows of W^T are the outputs of the input-gradient GEMMs
+            if ctx.needs_input_grad[0]:
+                gx = gemm_nt(gy, wt[:f], mask1=y)
+            if ctx.needs_input_grad[1]:
+                ga = gemm_nt(gy, wt[f:], mask1=y)
+        if ctx.needs_input_grad[2]:
+            gw = torch.empty_like(w_out)
+            gemm_tn(gy, x, mask=y, out=gw[:, :f])
+            gemm_tn(gy, aggr, mask=y, out=gw[:, f:])
+        return gx, ga, gw
+
+
+def _use_mfma(*ts) -> bool:
+    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+
+
+@torch.compiler.disable
+def project(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    if _use_mfma(x, w):
+        return _Project.apply(x, w)
+    return F.linear(x, w)
+
+
+@torch.compiler.disable
+def update(x: torch.Tensor, aggr: torch.Tensor, w_out: torch.Tensor) -> torch.Tensor:
+    if _use_mfma(x, aggr, w_out):
+        return _Update.apply(x, aggr, w_out)
+    f = x.size(1)
+    return F.relu(torch.addmm(F.linear(x, w_out[:, :f]), aggr, w_out[:, f:].t()))

@@ -18,15 +18,14 @@ import torch
 import torch.nn.functional as F
 from torch.nn import Linear
 
+from . import dense
 from .graph import graph_for
 from .ops import aggregate_fused, egnn_aggregate
 
 
 def _update(x: torch.Tensor, aggr: torch.Tensor, w_out: torch.Tensor) -> torch.Tensor:
     """relu(linear_out(cat[x, aggr])) without materialising the cat (models/layers.py:69,140)."""
-    f = x.size(1)
-    y = torch.addmm(F.linear(x, w_out[:, :f]), aggr, w_out[:, f:].t())
-    return F.relu(y)
+    return dense.update(x, aggr, w_out)
 
 
 class MPNNLayerCat(torch.nn.Module):
@@ -42,7 +41,7 @@ class MPNNLayerCat(torch.nn.Module):
         graph = graph_for(edge_index, x.size(0))
         # [Wi ; Wj] stacked row-wise gives the [N, 2H] table (target half, source half) in one GEMM.
         w_nodes = torch.cat([w[:, :f], w[:, f:2 * f]], dim=0)
-        ab = F.linear(x, w_nodes)
+        ab = dense.project(x, w_nodes)
         aggr = aggregate_fused(ab, edge_attr, w[:, 2 * f:], graph)
         return _update(x, aggr, self.linear_out.weight)
 
@@ -57,7 +56,7 @@ class MPNNLayerSum(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         graph = graph_for(edge_index, x.size(0))
-        ab = self.fused_linear(x)  # xs = ab[:, :H] (target), xt = ab[:, H:] (source)
+        ab = dense.project(x, self.fused_linear.weight)  # xs = ab[:, :H] (target), xt = ab[:, H:] (source)
         aggr = aggregate_fused(ab, edge_attr, self.linear_3.weight, graph)
         return _update(x, aggr, self.linear_out.weight)
 
@@ -80,7 +79,7 @@ class EGNNLayer(torch.nn.Module):
 
     def forward(self, x, pos, edge_index, edge_attr):
         graph = graph_for(edge_index, x.size(0))
-        ab = self.fused_linear(x)
+        ab = dense.project(x, self.fused_linear.weight)
         h = self.out_channels
         aggr, pos_out = egnn_aggregate(ab[:, :h], ab[:, h:], edge_attr, self.linear_3.weight, pos.float(),
                                        self.coord_linear.weight.view(-1), graph)

@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import ops
+from . import dense, ops
 from .graph import MPGraph
 from .layers import MPNNLayerCat, MPNNLayerSum, _update
 
@@ -112,12 +112,12 @@ def partitioned_layer(layer, x_local: torch.Tensor, pg: PartitionedGraph, edge_a
     """One MPNN layer on the local destination range (same arithmetic as layer.forward on the whole graph)."""
     aggregate_fn = aggregate_fn or ops.aggregate
     if isinstance(layer, MPNNLayerSum):
-        ab = layer.fused_linear(x_local)
+        ab = dense.project(x_local, layer.fused_linear.weight)
         w_edge = layer.linear_3.weight
     elif isinstance(layer, MPNNLayerCat):
         f = layer.in_channels
         w = layer.linear.weight
-        ab = F.linear(x_local, torch.cat([w[:, :f], w[:, f:2 * f]], dim=0))
+        ab = dense.project(x_local, torch.cat([w[:, :f], w[:, f:2 * f]], dim=0))
         w_edge = w[:, 2 * f:]
     else:
         raise TypeError(f"unsupported layer type {type(layer).__name__}")

@@ -319,3 +319,44 @@ def test_egnn_layer_module(dev):
     assert_close(h, O.update(g["x"], want_aggr, layer.linear_out.weight.detach().cpu()), RTOL32, what="layer h")
     (h.sum() + pos.sum()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in layer.parameters())
+
+
+# --------------------------------------------------------------------------- dense MFMA GEMMs (fp32)
+# Floating-point kernels: checked against torch float64 matmul of the same operands.
+@pytest.mark.parametrize("n,k1,k2,m,relu", [
+    (1000, 128, 0, 256, False),    # fused projection, hidden 128
+    (777, 500, 64, 64, True),      # Flickr layer-1 update: x | aggr
+    (300, 11, 64, 64, True),       # QM9 layer-1 update (unaligned K)
+    (129, 3, 0, 128, False),       # ModelNet projection (K = 3)
+    (260, 64, 0, 500, False),      # input gradient towards 500 features (two column slices)
+    (64, 20, 12, 7, True),
+])
+def test_gemm_nt(n, k1, k2, m, relu, dev):
+    from mpnn_amd.dense import gemm_nt
+    gen = torch.Generator().manual_seed(n + m)
+    x1, w1 = torch.randn(n, k1, generator=gen), torch.randn(m, k1 + k2, generator=gen)
+    x2 = torch.randn(n, k2, generator=gen) if k2 else None
+    mask = torch.randn(n, k1, generator=gen)
+    want = (x1.double() * (mask > 0)) @ w1[:, :k1].double().t()
+    if k2:
+        want = want + x2.double() @ w1[:, k1:].double().t()
+    if relu:
+        want = want.relu()
+    wd = w1.to(dev)
+    got = gemm_nt(x1.to(dev), wd[:, :k1], x2.to(dev) if k2 else None, wd[:, k1:] if k2 else None,
+                  mask1=mask.to(dev), relu=relu)
+    assert_close(got, want, RTOL32, what="gemm_nt")
+
+
+@pytest.mark.parametrize("n,m,k", [(5000, 256, 128), (3001, 64, 500), (100, 64, 11), (33, 7, 3), (4096, 128, 130)])
+def test_gemm_tn(n, m, k, dev):
+    from mpnn_amd.dense import gemm_tn
+    gen = torch.Generator().manual_seed(n + k)
+    g, x, mask = torch.randn(n, m, generator=gen), torch.randn(n, k, generator=gen), torch.randn(n, m, generator=gen)
+    want = (g.double() * (mask > 0)).t() @ x.double()
+    wide = torch.zeros(m, k + 5, device=dev)
+    got = gemm_tn(g.to(dev), x.to(dev), mask=mask.to(dev), out=wide[:, 5:])
+    assert_close(got, want, RTOL32, what="gemm_tn")
+    assert float(wide[:, :5].abs().sum()) == 0.0
+    again = gemm_tn(g.to(dev), x.to(dev), mask=mask.to(dev))
+    assert torch.equal(again, got.contiguous()), "weight gradient is not bitwise reproducible"
