@@ -40,100 +40,169 @@ struct NtArgs {
   int relu;
 };
 
+// Branch-free 4-float load at columns k..k+3 of a row of K floats.  The address is clamped into the row so
+// the load can always be issued (a branch around a load makes the compiler drain every outstanding load
+// first); columns >= K are zeroed afterwards with select4().  ALIGNED requires K % 4 == 0 and k % 4 == 0.
 template <bool ALIGNED>
 __device__ __forceinline__ float4 load_chunk4(const float* row, int k, int K) {
   if (ALIGNED) {
-    if (k + 3 < K) return *reinterpret_cast<const float4*>(row + k);
+    const int kk = k < K ? k : K - 4;
+    return *reinterpret_cast<const float4*>(row + kk);
   }
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k < K) v.x = row[k];
-  if (k + 1 < K) v.y = row[k + 1];
-  if (k + 2 < K) v.z = row[k + 2];
-  if (k + 3 < K) v.w = row[k + 3];
+  const int last = K - 1;
+  float4 v;
+  v.x = row[k < last ? k : last];
+  v.y = row[k + 1 < last ? k + 1 : last];
+  v.z = row[k + 2 < last ? k + 2 : last];
+  v.w = row[k + 3 < last ? k + 3 : last];
   return v;
 }
 
-// MT = number of 32-column output tiles per wave (M <= 32 * MT per gridDim.y slice).
-template <int MT, bool ALIGNED>
-__global__ void __launch_bounds__(kBlock) k_gemm_nt(NtArgs a) {
+// bit j set <=> column k + j exists (and the row does)
+__device__ __forceinline__ int valid4(int k, int K, bool row_ok) {
+  if (!row_ok) return 0;
+  return (k < K ? 1 : 0) | (k + 1 < K ? 2 : 0) | (k + 2 < K ? 4 : 0) | (k + 3 < K ? 8 : 0);
+}
+
+__device__ __forceinline__ float4 select4(float4 v, int vm) {
+  v.x = (vm & 1) ? v.x : 0.f; v.y = (vm & 2) ? v.y : 0.f;
+  v.z = (vm & 4) ? v.z : 0.f; v.w = (vm & 8) ? v.w : 0.f;
+  return v;
+}
+
+__device__ __forceinline__ float4 relu_mask4(float4 v, float4 m) {
+  v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+  v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+  return v;
+}
+
+// MT = 32-column output tiles per wave, WC = wave columns: a block is 4 x WC waves; wave (wr, wc) owns rows
+// [32 wr, 32 wr + 32) of the 128-row step and columns [32 MT wc, 32 MT (wc + 1)) of the block's column slice.
+// k-chunks are software-pipelined: while chunk c is multiplied out of one LDS buffer, chunk c + 1 is in
+// flight from global memory into registers and is written to the other buffer before the (single) barrier.
+template <int MT, int WC, bool ALIGNED>
+__global__ void __launch_bounds__(kBlock * WC) k_gemm_nt(NtArgs a) {
+  constexpr int NTHREADS = kBlock * WC;
+  constexpr int WROWS = 32 * MT * WC;
+  constexpr int XQ = (kBN * (kBK / 4)) / NTHREADS;                   // float4 of X per thread and chunk
+  constexpr int WQ = (WROWS * (kBK / 4) + NTHREADS - 1) / NTHREADS;  // float4 of W per thread and chunk
+  constexpr int STAGE = (kBN + WROWS) * kLd;
   extern __shared__ float lds[];
-  float* Xs = lds;                      // [kBN][kLd]
-  float* Ws = lds + kBN * kLd;          // [32*MT][kLd]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
+  const int wr = wid & 3, wc = wid >> 2;
   const int li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.y * (32 * MT);
+  const int m0 = blockIdx.y * WROWS;
+  const int nch0 = (a.seg[0].K + kBK - 1) / kBK;
+  const int nch = nch0 + (a.nseg > 1 ? (a.seg[1].K + kBK - 1) / kBK : 0);
 
-  for (int64_t row0 = (int64_t)blockIdx.x * kBN; row0 < a.N; row0 += (int64_t)gridDim.x * kBN) {
-    f32x16 acc[MT];
-#pragma unroll
-    for (int c = 0; c < MT; ++c)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  // The (row step, k-chunk) pairs of this block form one flat sequence, so the first chunk of the next
+  // row step is already in flight while the last chunk of the current one is multiplied and stored.
+  const int64_t nsteps_all = (a.N + kBN - 1) / kBN;
+  const int64_t my_steps = blockIdx.x < nsteps_all ? (nsteps_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t total = my_steps * nch;
 
-    for (int s = 0; s < a.nseg; ++s) {
-      const NtSegment sg = a.seg[s];
-      for (int k0 = 0; k0 < sg.K; k0 += kBK) {
-        __syncthreads();
-        // stage X chunk: 128 rows x 8 float4
+  f32x16 acc[MT];
 #pragma unroll
-        for (int q = 0; q < (kBN * (kBK / 4)) / kBlock; ++q) {
-          const int idx = tid + kBlock * q;
-          const int r = idx >> 3, c4 = (idx & 7) * 4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (row0 + r < a.N) {
-            v = load_chunk4<ALIGNED>(sg.X + (row0 + r) * sg.ldx, k0 + c4, sg.K);
-            if (sg.mask) {
-              const float4 mk = load_chunk4<ALIGNED>(sg.mask + (row0 + r) * sg.ldm, k0 + c4, sg.K);
-              v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-              v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-            }
-          }
-          *reinterpret_cast<float4*>(Xs + r * kLd + c4) = v;
-        }
-        // stage W chunk: 32*MT rows x 8 float4
+  for (int c = 0; c < MT; ++c)
 #pragma unroll
-        for (int q = 0; q < (32 * MT * (kBK / 4) + kBlock - 1) / kBlock; ++q) {
-          const int idx = tid + kBlock * q;
-          const int r = idx >> 3, c4 = (idx & 7) * 4;
-          if (r < 32 * MT) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < a.M) v = load_chunk4<ALIGNED>(sg.W + (int64_t)(m0 + r) * sg.ldw, k0 + c4, sg.K);
-            *reinterpret_cast<float4*>(Ws + r * kLd + c4) = v;
-          }
-        }
-        __syncthreads();
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+  float4 xr[XQ], mr[XQ], wreg[WQ];
+  int xv[XQ], wv[WQ];
+  bool masked = false;
+
+  auto fetch = [&](int64_t row0, int c) {
+    const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
+    const int k0 = (c < nch0 ? c : c - nch0) * kBK;
+    masked = sg.mask != nullptr;
 #pragma unroll
-        for (int kq = 0; kq < kBK / 8; ++kq) {
-          const float4 av = *reinterpret_cast<const float4*>(Xs + (wid * 32 + li) * kLd + kq * 8 + lh * 4);
+    for (int q = 0; q < XQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      const int c4 = (idx & 7) * 4;
+      int64_t row = row0 + (idx >> 3);
+      row = row < a.N ? row : a.N - 1;   // rows past the end compute garbage that is never stored
+      xr[q] = load_chunk4<ALIGNED>(sg.X + row * sg.ldx, k0 + c4, sg.K);
+      if (masked) mr[q] = load_chunk4<ALIGNED>(sg.mask + row * sg.ldm, k0 + c4, sg.K);
+      xv[q] = valid4(k0 + c4, sg.K, true);
+    }
 #pragma unroll
-          for (int c = 0; c < MT; ++c) {
-            const float4 bv = *reinterpret_cast<const float4*>(Ws + (c * 32 + li) * kLd + kq * 8 + lh * 4);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[c], 0, 0, 0);
-          }
-        }
+    for (int q = 0; q < WQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      const int c4 = (idx & 7) * 4;
+      int r = m0 + (idx >> 3);
+      r = r < a.M ? r : a.M - 1;
+      wreg[q] = load_chunk4<ALIGNED>(sg.W + (int64_t)r * sg.ldw, k0 + c4, sg.K);
+      wv[q] = valid4(k0 + c4, sg.K, true);
+    }
+  };
+  auto stash = [&](int buf) {
+    float* Xs = lds + buf * STAGE;
+    float* Ws = Xs + kBN * kLd;
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      float4 v = select4(xr[q], xv[q]);
+      if (masked) v = relu_mask4(v, mr[q]);  // relu backward fused into the operand
+      *reinterpret_cast<float4*>(Xs + (idx >> 3) * kLd + (idx & 7) * 4) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      if ((idx >> 3) < WROWS)
+        *reinterpret_cast<float4*>(Ws + (idx >> 3) * kLd + (idx & 7) * 4) = select4(wreg[q], wv[q]);
+    }
+  };
+
+  if (total > 0) {
+    fetch((int64_t)blockIdx.x * kBN, 0);
+    stash(0);
+  }
+  __syncthreads();
+  int64_t step = 0;
+  int c = 0;
+  for (int64_t it = 0; it < total; ++it) {
+    const int buf = (int)(it & 1);
+    const int64_t row0 = (blockIdx.x + step * gridDim.x) * kBN;
+    const bool last_chunk = c + 1 == nch;
+    if (it + 1 < total) fetch(last_chunk ? row0 + (int64_t)gridDim.x * kBN : row0, last_chunk ? 0 : c + 1);
+    const float* Xs = lds + buf * STAGE;
+    const float* Ws = Xs + kBN * kLd;
+#pragma unroll
+    for (int kq = 0; kq < kBK / 8; ++kq) {
+      const float4 av = *reinterpret_cast<const float4*>(Xs + (wr * 32 + li) * kLd + kq * 8 + lh * 4);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const float4 bv = *reinterpret_cast<const float4*>(Ws + ((wc * MT + t) * 32 + li) * kLd + kq * 8 + lh * 4);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
       }
     }
-    // C layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (last_chunk) {
+      // C layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int c = 0; c < MT; ++c) {
-      const int col = m0 + c * 32 + li;
-      if (col < a.M) {
+      for (int t = 0; t < MT; ++t) {
+        const int col = m0 + (wc * MT + t) * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < a.N) {
-            float v = acc[c][r];
+          const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (col < a.M && row < a.N) {
+            float v = acc[t][r];
             if (a.relu) v = v <= 0.f ? 0.f : v;
             a.Y[row * a.ldy + col] = v;
           }
+          acc[t][r] = 0.f;
         }
       }
+      ++step;
+      c = 0;
+    } else {
+      ++c;
     }
+    if (it + 1 < total) stash(buf ^ 1);
+    __syncthreads();
   }
 }
 
@@ -146,10 +215,11 @@ struct TnArgs {
 };
 
 // Output tile 128 (m) x 128 (k) per block; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles).
+// Row slabs are software-pipelined like the k-chunks of k_gemm_nt (two LDS buffers, one barrier per slab).
 template <bool ALIGNED>
 __global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
-  __shared__ float Gs[32][128];
-  __shared__ float Xs[32][128];
+  __shared__ float Gs[2][32][128];
+  __shared__ float Xs[2][32][128];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
@@ -165,36 +235,57 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int64_t n0 = (int64_t)blockIdx.x * 32; n0 < a.N; n0 += (int64_t)gridDim.x * 32) {
-    __syncthreads();
+  float4 gr[4], mr[4], xr[4];
+  int gv[4], xv[4];
+  auto fetch = [&](int64_t n0) {
 #pragma unroll
-    for (int q = 0; q < (32 * 32) / kBlock; ++q) {  // 32 rows x 32 float4 per matrix
+    for (int q = 0; q < 4; ++q) {  // 32 rows x 32 float4 per matrix
       const int idx = tid + kBlock * q;
-      const int r = idx >> 5, c4 = (idx & 31) * 4;
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), x = g;
-      if (n0 + r < a.N) {
-        g = load_chunk4<ALIGNED>(a.G + (n0 + r) * a.ldg, m0 + c4, a.M);
-        if (a.mask) {
-          const float4 mk = load_chunk4<ALIGNED>(a.mask + (n0 + r) * a.ldm, m0 + c4, a.M);
-          g.x = mk.x > 0.f ? g.x : 0.f; g.y = mk.y > 0.f ? g.y : 0.f;
-          g.z = mk.z > 0.f ? g.z : 0.f; g.w = mk.w > 0.f ? g.w : 0.f;
-        }
-        x = load_chunk4<ALIGNED>(a.X + (n0 + r) * a.ldx, k0 + c4, a.K);
-      }
-      *reinterpret_cast<float4*>(&Gs[r][c4]) = g;
-      *reinterpret_cast<float4*>(&Xs[r][c4]) = x;
+      const int c4 = (idx & 31) * 4;
+      int64_t row = n0 + (idx >> 5);
+      const bool row_ok = row < a.N;   // rows past the end must contribute exact zeros to the sums
+      row = row_ok ? row : a.N - 1;
+      gr[q] = load_chunk4<ALIGNED>(a.G + row * a.ldg, m0 + c4, a.M);
+      if (a.mask) mr[q] = load_chunk4<ALIGNED>(a.mask + row * a.ldm, m0 + c4, a.M);
+      xr[q] = load_chunk4<ALIGNED>(a.X + row * a.ldx, k0 + c4, a.K);
+      gv[q] = valid4(m0 + c4, a.M, row_ok);
+      xv[q] = valid4(k0 + c4, a.K, row_ok);
     }
-    __syncthreads();
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + kBlock * q;
+      float4 g = select4(gr[q], gv[q]);
+      if (a.mask) g = relu_mask4(g, mr[q]);
+      *reinterpret_cast<float4*>(&Gs[buf][idx >> 5][(idx & 31) * 4]) = g;
+      *reinterpret_cast<float4*>(&Xs[buf][idx >> 5][(idx & 31) * 4]) = select4(xr[q], xv[q]);
+    }
+  };
+
+  const int64_t step = (int64_t)gridDim.x * 32;
+  int64_t n0 = (int64_t)blockIdx.x * 32;
+  int buf = 0;
+  if (n0 < a.N) {
+    fetch(n0);
+    stash(0);
+  }
+  __syncthreads();
+  for (; n0 < a.N; n0 += step, buf ^= 1) {
+    const bool more = n0 + step < a.N;
+    if (more) fetch(n0 + step);
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int n = 2 * t + lh;
-      const float a0 = Gs[n][wm + li], a1 = Gs[n][wm + 32 + li];
-      const float b0 = Xs[n][wk + li], b1 = Xs[n][wk + 32 + li];
+      const float a0 = Gs[buf][n][wm + li], a1 = Gs[buf][n][wm + 32 + li];
+      const float b0 = Xs[buf][n][wk + li], b1 = Xs[buf][n][wk + 32 + li];
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
   }
   float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
 #pragma unroll
@@ -223,7 +314,7 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict
 
 static int tn_slabs(int64_t N, int M, int K) {
   const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
-  int slabs = 768 / tiles;  // about 3 resident blocks per CU in total
+  int slabs = 512 / tiles;  // two resident blocks (64 KiB of LDS each) per CU in total
   if (slabs < 1) slabs = 1;
   const int64_t need = (N + 31) / 32;
   if (slabs > need) slabs = (int)(need < 1 ? 1 : need);
@@ -233,20 +324,21 @@ static int tn_slabs(int64_t N, int M, int K) {
 static bool nt_aligned(const NtArgs& a) {
   for (int s = 0; s < a.nseg; ++s) {
     const NtSegment& g = a.seg[s];
-    if (((uintptr_t)g.X & 15) || ((uintptr_t)g.W & 15) || (g.ldx & 3) || (g.ldw & 3)) return false;
+    if (((uintptr_t)g.X & 15) || ((uintptr_t)g.W & 15) || (g.ldx & 3) || (g.ldw & 3) || (g.K & 3)) return false;
     if (g.mask && (((uintptr_t)g.mask & 15) || (g.ldm & 3))) return false;
   }
   return true;
 }
 
-template <int MT>
+template <int MT, int WC>
 static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
   int64_t blocks = (a.N + kBN - 1) / kBN;
   if (blocks > 1024) blocks = 1024;
-  dim3 grid((unsigned)blocks, (a.M + 32 * MT - 1) / (32 * MT));
-  const size_t lds = (size_t)(kBN + 32 * MT) * kLd * sizeof(float);
-  if (aligned) k_gemm_nt<MT, true><<<grid, kBlock, lds, stream>>>(a);
-  else k_gemm_nt<MT, false><<<grid, kBlock, lds, stream>>>(a);
+  constexpr int WROWS = 32 * MT * WC;
+  dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
+  const size_t lds = (size_t)2 * (kBN + WROWS) * kLd * sizeof(float);
+  if (aligned) k_gemm_nt<MT, WC, true><<<grid, kBlock * WC, lds, stream>>>(a);
+  else k_gemm_nt<MT, WC, false><<<grid, kBlock * WC, lds, stream>>>(a);
 }
 
 }  // namespace mpnn
@@ -270,10 +362,10 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
   a.nseg = K2 > 0 ? 2 : 1;
   a.Y = Y; a.ldy = ldy; a.N = N; a.M = M; a.relu = relu;
   const bool aligned = nt_aligned(a);
-  if (M <= 32) launch_nt<1>(a, aligned, stream);
-  else if (M <= 64) launch_nt<2>(a, aligned, stream);
-  else if (M <= 128) launch_nt<4>(a, aligned, stream);
-  else launch_nt<8>(a, aligned, stream);
+  if (M <= 32) launch_nt<1, 1>(a, aligned, stream);
+  else if (M <= 64) launch_nt<2, 1>(a, aligned, stream);
+  else if (M <= 128) launch_nt<4, 1>(a, aligned, stream);
+  else launch_nt<4, 2>(a, aligned, stream);
   MPNN_LAUNCH_CHECK("k_gemm_nt");
   return MPNN_OK;
 }
@@ -297,7 +389,7 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
   if (ldg < M || ldx < K || (mask && ldm < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: leading dimension too small");
   TnArgs a{G, ldg, mask, ldm, X, ldx, scratch, N, M, K};
   const int slabs = tn_slabs(N, M, K);
-  const bool aligned = !(((uintptr_t)G & 15) || ((uintptr_t)X & 15) || (ldg & 3) || (ldx & 3) ||
+  const bool aligned = !(((uintptr_t)G & 15) || ((uintptr_t)X & 15) || (ldg & 3) || (ldx & 3) || (M & 3) || (K & 3) ||
                          (mask && (((uintptr_t)mask & 15) || (ldm & 3))));
   dim3 grid(slabs, (M + 127) / 128, (K + 127) / 128);
   if (aligned) k_gemm_tn<true><<<grid, kBlock, 0, stream>>>(a);
