@@ -111,6 +111,11 @@ def cpu_baseline(name, mode, target_seconds=20.0):
     }
 
 
+def note(msg):
+    """Progress line on stderr (stdout carries only the JSON result)."""
+    print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,18 +126,28 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
 
+    if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from mpnn_amd import MPNNLayerCat, MPNNLayerSum, ops
     from mpnn_amd.partition import PartitionedGraph, allreduce_gradients, partitioned_layer
@@ -141,6 +156,7 @@ def main():
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
     s = 4 if args.dtype == "f32" else 2
 
+    note("generating the synthetic graph")
     d = make_data(args.workload, dev, scale=args.scale, seed=0)
     n_total, e_total = d["num_nodes"], d["edge_index"].size(1)
     F_in, H, Fe = d["x"].size(1), cfg["H"], d["edge_attr"].size(1)
@@ -162,6 +178,7 @@ def main():
         forward = lambda: partitioned_layer(layer, x, pg, ea)
     del d
     torch.cuda.empty_cache()
+    note("graph structures built; warming up")
     gen = torch.Generator(device=dev).manual_seed(2)
     r = torch.randn(x.size(0), H, generator=gen, device=dev).to(dtype)
 
@@ -182,6 +199,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    note("timing")
     ops.EVENT_SINK = []
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -83,7 +83,8 @@ int32_t mpnn_csr_build(const int64_t* key, const int64_t* other, int64_t num_edg
  *                                                    else the piece's partial-sum slot
  *   split[4*s .. 4*s+3] = { row, first pslot, pieces, first item }
  *   meta[0..2]          = { number of items, number of partial slots, number of split rows }
- * Items of split rows come first, then unsplit rows in row order.
+ * Items of split rows come first (row order, piece order), then unsplit rows by descending
+ * degree (row order among equal degrees), so that the lane groups of a wave get items of like length.
  * Capacity needed: items <= N + E/chunk + 1 ; split <= E/(chunk+1) + 1.
  */
 int64_t mpnn_items_workspace_bytes(int64_t num_nodes);

@@ -15,6 +15,8 @@
 //     float scratch slab and are combined in piece order by k_reduce_split.
 //   * Source indices of an item are fetched LPR at a time with one coalesced load and handed
 //     round the group with ds_bpermute; U row gathers per lane are kept in flight.
+#include <stdlib.h>
+
 #include "edgeops.h"
 
 namespace mpnn {
@@ -282,14 +284,31 @@ __global__ void __launch_bounds__(kBlock) k_segment_mean_bwd(const T* __restrict
 // ---------------------------------------------------------------------------------------
 // Host-side dispatch
 // ---------------------------------------------------------------------------------------
-template <typename T, int VEC, bool TRAIN>
-static int32_t launch_fwd(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
-  constexpr int U = 4;
+// Row gathers kept in flight per lane by the forward kernel (tuning knob; MPNN_FWD_U=2|4|8 overrides).
+static int fwd_unroll() {
+  static int u = [] {
+    const char* e = getenv("MPNN_FWD_U");
+    int v = e ? atoi(e) : 4;
+    return (v == 2 || v == 8) ? v : 4;
+  }();
+  return u;
+}
+
+template <typename T, int VEC, bool TRAIN, int U>
+static int32_t launch_fwd_u(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
   if (a.fe == 4) k_agg_fwd<T, VEC, 4, false, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
   else if (a.fe == 1) k_agg_fwd<T, VEC, 1, false, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
   else k_agg_fwd<T, VEC, kMaxFe, true, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
   MPNN_LAUNCH_CHECK("k_agg_fwd");
   return MPNN_OK;
+}
+
+template <typename T, int VEC, bool TRAIN>
+static int32_t launch_fwd(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
+  const int u = fwd_unroll();
+  if (u == 2) return launch_fwd_u<T, VEC, TRAIN, 2>(a, grid, stream);
+  if (u == 8) return launch_fwd_u<T, VEC, TRAIN, 8>(a, grid, stream);
+  return launch_fwd_u<T, VEC, TRAIN, 4>(a, grid, stream);
 }
 
 template <typename T, int VEC>

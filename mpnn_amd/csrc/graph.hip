@@ -89,8 +89,11 @@ __device__ __forceinline__ int piece_size(int deg, int chunk, int max_parts) {
 
 // counts[0][n] = partial slots of row n (0 if unsplit), counts[1][n] = 1 if row n is split.
 // Entry n == N is a zero terminator so that an exclusive scan over N+1 entries ends in the total.
+// key[n] orders the rows for the item list: split rows first (key 0, row order), then unsplit rows by
+// DESCENDING degree (key = 1 + chunk - deg), row order among equal degrees (the sort is stable).
 __global__ void k_item_counts(const int32_t* __restrict__ rowptr, int64_t N, int chunk, int max_parts,
-                              int32_t* __restrict__ c_parts, int32_t* __restrict__ c_split) {
+                              int32_t* __restrict__ c_parts, int32_t* __restrict__ c_split,
+                              int32_t* __restrict__ key) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n <= N; n += stride) {
     int parts = 0, split = 0;
@@ -101,6 +104,7 @@ __global__ void k_item_counts(const int32_t* __restrict__ rowptr, int64_t N, int
         parts = (deg + ps - 1) / ps;
         split = 1;
       }
+      key[n] = split ? 0 : 1 + chunk - deg;
     }
     c_parts[n] = parts;
     c_split[n] = split;
@@ -109,24 +113,25 @@ __global__ void k_item_counts(const int32_t* __restrict__ rowptr, int64_t N, int
 
 __global__ void k_item_fill_rows(const int32_t* __restrict__ rowptr, int64_t N, int chunk, int max_parts,
                                  const int32_t* __restrict__ o_parts, const int32_t* __restrict__ o_split,
-                                 int4* __restrict__ items, int64_t items_cap, int4* __restrict__ split,
-                                 int64_t split_cap, int32_t* __restrict__ meta) {
+                                 const int32_t* __restrict__ order, int4* __restrict__ items, int64_t items_cap,
+                                 int4* __restrict__ split, int64_t split_cap, int32_t* __restrict__ meta) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int n_parts = o_parts[N];
   const int n_split = o_split[N];
   bool overflow = false;
-  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < N; j += stride) {
+    const int n = order[j];  // j-th row in (split first, then descending degree) order
     int r0 = rowptr[n], r1 = rowptr[n + 1];
     int deg = r1 - r0;
     if (deg <= chunk) {
-      int64_t idx = (int64_t)n_parts + n - o_split[n];
-      if (idx < items_cap) items[idx] = make_int4((int)n, r0, r1, -1);
+      int64_t idx = (int64_t)n_parts + j - n_split;
+      if (idx < items_cap) items[idx] = make_int4(n, r0, r1, -1);
       else overflow = true;
     } else {
       int ps = piece_size(deg, chunk, max_parts);
       int pieces = (deg + ps - 1) / ps;
-      int64_t idx = o_split[n];
-      if (idx < split_cap) split[idx] = make_int4((int)n, o_parts[n], pieces, o_parts[n]);
+      int64_t idx = o_split[n];  // == j: split rows keep row order at the front
+      if (idx < split_cap) split[idx] = make_int4(n, o_parts[n], pieces, o_parts[n]);
       else overflow = true;
     }
   }
@@ -163,6 +168,19 @@ __global__ void k_item_fill_pieces(const int32_t* __restrict__ rowptr, int64_t N
     }
   }
   if (overflow) meta[3] = 1;
+}
+
+static unsigned order_bits(int chunk) {
+  unsigned b = 1;
+  while (b < 31 && (1 << b) < chunk + 2) ++b;
+  return b;
+}
+
+static hipError_t order_temp_bytes(int64_t N, int chunk, size_t& bytes) {
+  bytes = 0;
+  int32_t* kn = nullptr;
+  return rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0), kn, (size_t)N, 0u,
+                                   order_bits(chunk), (hipStream_t)0);
 }
 
 static hipError_t scan_temp_bytes(int64_t n, size_t& bytes) {
@@ -241,11 +259,19 @@ int32_t mpnn_csr_build(const int64_t* key, const int64_t* other, int64_t E, int6
   return MPNN_OK;
 }
 
+// The radix sort's temporary storage is sized for the widest key the rule can produce (chunk < 2^30).
+static int64_t items_temp_bytes(int64_t N) {
+  size_t t1 = 0, t2 = 0;
+  if (scan_temp_bytes(N + 1, t1) != hipSuccess) return -1;
+  if (order_temp_bytes(N, (1 << 30) - 2, t2) != hipSuccess) return -1;
+  return (int64_t)(t1 > t2 ? t1 : t2);
+}
+
 int64_t mpnn_items_workspace_bytes(int64_t N) {
   if (N < 0 || N >= INT32_MAX) return -1;
-  size_t temp = 0;
-  if (scan_temp_bytes(N + 1, temp) != hipSuccess) return -1;
-  return 4 * align_up((N + 1) * 4, 256) + align_up((int64_t)temp + 256, 256);
+  const int64_t temp = items_temp_bytes(N);
+  if (temp < 0) return -1;
+  return 7 * align_up((N + 1) * 4, 256) + align_up(temp + 256, 256);
 }
 
 int32_t mpnn_items_build(const int32_t* rowptr, int64_t N, int32_t chunk, int32_t max_parts, int32_t* items,
@@ -263,14 +289,18 @@ int32_t mpnn_items_build(const int32_t* rowptr, int64_t N, int32_t chunk, int32_
   int32_t* c_split = arena.take<int32_t>(N + 1);
   int32_t* o_parts = arena.take<int32_t>(N + 1);
   int32_t* o_split = arena.take<int32_t>(N + 1);
-  size_t temp = 0;
-  MPNN_HIP_CHECK(scan_temp_bytes(N + 1, temp));
+  int32_t* key = arena.take<int32_t>(N + 1);
+  int32_t* key_sorted = arena.take<int32_t>(N + 1);
+  int32_t* order = arena.take<int32_t>(N + 1);
+  const int64_t temp_need = items_temp_bytes(N);
+  if (temp_need < 0) return fail(MPNN_E_HIP, "mpnn_items_build: rocPRIM size query failed");
+  size_t temp = (size_t)temp_need;
   char* temp_ptr = arena.take<char>((int64_t)temp + 256);
-  if (!c_parts || !c_split || !o_parts || !o_split || !temp_ptr)
+  if (!c_parts || !c_split || !o_parts || !o_split || !key || !key_sorted || !order || !temp_ptr)
     return fail(MPNN_E_WORKSPACE, "mpnn_items_build: workspace of %lld bytes is too small (need %lld)",
                 (long long)workspace_bytes, (long long)mpnn_items_workspace_bytes(N));
   MPNN_HIP_CHECK(hipMemsetAsync(meta, 0, 8 * sizeof(int32_t), stream));
-  k_item_counts<<<grid_for(N + 1), kBlock, 0, stream>>>(rowptr, N, chunk, max_parts, c_parts, c_split);
+  k_item_counts<<<grid_for(N + 1), kBlock, 0, stream>>>(rowptr, N, chunk, max_parts, c_parts, c_split, key);
   MPNN_LAUNCH_CHECK("k_item_counts");
   size_t t1 = temp;
   MPNN_HIP_CHECK(rocprim::exclusive_scan(temp_ptr, t1, c_parts, o_parts, 0, (size_t)(N + 1),
@@ -278,7 +308,12 @@ int32_t mpnn_items_build(const int32_t* rowptr, int64_t N, int32_t chunk, int32_
   size_t t2 = temp;
   MPNN_HIP_CHECK(rocprim::exclusive_scan(temp_ptr, t2, c_split, o_split, 0, (size_t)(N + 1),
                                          rocprim::plus<int32_t>(), stream));
-  k_item_fill_rows<<<grid_for(N), kBlock, 0, stream>>>(rowptr, N, chunk, max_parts, o_parts, o_split,
+  if (N > 0) {
+    size_t t3 = temp;
+    MPNN_HIP_CHECK(rocprim::radix_sort_pairs(temp_ptr, t3, key, key_sorted, rocprim::counting_iterator<int32_t>(0),
+                                             order, (size_t)N, 0u, order_bits(chunk), stream));
+  }
+  k_item_fill_rows<<<grid_for(N), kBlock, 0, stream>>>(rowptr, N, chunk, max_parts, o_parts, o_split, order,
                                                        reinterpret_cast<int4*>(items), items_capacity,
                                                        reinterpret_cast<int4*>(split), split_capacity, meta);
   MPNN_LAUNCH_CHECK("k_item_fill_rows");

@@ -181,7 +181,8 @@ def work_items(rowptr: torch.Tensor, chunk: int, max_parts: int):
 
     A row with deg <= chunk is one item.  A longer row is cut into pieces of
     ``max(chunk, ceil(deg / max_parts))`` edges.  Items of split rows come first
-    (row order, piece order), then the unsplit rows in row order.  Each item is
+    (row order, piece order), then the unsplit rows by descending degree (row order
+    among equal degrees).  Each item is
     (row, e0, e1, pslot) with pslot = -1 for unsplit rows and the running piece
     number otherwise.  Split rows are listed as (row, first pslot, pieces, first item).
     """
@@ -200,10 +201,10 @@ def work_items(rowptr: torch.Tensor, chunk: int, max_parts: int):
             e0 = rp[r] + c * size
             split_items.append((r, e0, min(e0 + size, rp[r + 1]), pslot))
             pslot += 1
-    for r in range(n):
-        deg = rp[r + 1] - rp[r]
-        if deg <= chunk:
-            plain_items.append((r, rp[r], rp[r + 1], -1))
+    plain = [r for r in range(n) if rp[r + 1] - rp[r] <= chunk]
+    plain.sort(key=lambda r: -(rp[r + 1] - rp[r]))  # list.sort is stable: ties stay in row order
+    for r in plain:
+        plain_items.append((r, rp[r], rp[r + 1], -1))
     items = torch.tensor(split_items + plain_items, dtype=torch.int32).reshape(-1, 4)
     split = torch.tensor(split_rows, dtype=torch.int32).reshape(-1, 4)
     return items, split, pslot

@@ -1,0 +1,40 @@
+"""Times the two edge kernels on a power-law graph (default 1/4 of the S3DIS-scale workload)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mpnn_amd import synth, ops
+from mpnn_amd.graph import MPGraph
+from mpnn_amd.ops import aggregate_fused
+
+dev = torch.device("cuda:0")
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
+H = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+kind = sys.argv[3] if len(sys.argv) > 3 else "powerlaw"
+n, e = int(4_000_000 * scale), int(100_000_000 * scale)
+if kind == "powerlaw":
+    d = synth.powerlaw(dev, 0, n, e, 8, 4)
+else:
+    d = {"edge_index": torch.randint(0, n, (2, e), device=dev), "edge_attr": torch.rand(e, 4, device=dev)}
+g = MPGraph(d["edge_index"], n)
+ab = torch.randn(n, 2 * H, device=dev, requires_grad=True)
+we = torch.randn(H, 4, device=dev, requires_grad=True)
+r = torch.randn(n, H, device=dev)
+for it in range(3):
+    ops.EVENT_SINK = []
+    for _ in range(5):
+        ab.grad = None; we.grad = None
+        out = aggregate_fused(ab, d["edge_attr"], we, g)
+        out.backward(r)
+    torch.cuda.synchronize()
+    ev = ops.EVENT_SINK; ops.EVENT_SINK = None
+t = {}
+for name, a, b in ev:
+    t.setdefault(name, []).append(a.elapsed_time(b))
+s = 4
+for k, v in t.items():
+    ms = sorted(v)[len(v) // 2]
+    if k == "aggregate_fwd":
+        by = e * (4 + H * s + 4 * s) + n * (16 + 2 * H * s + 4 * H)
+    else:
+        by = e * (4 + 2 * H * s + 4 * s) + n * (16 + 2 * H * s)
+    print(f"{kind} scale={scale} H={H} U={os.environ.get('MPNN_FWD_U','4')} {k}: {ms:.3f} ms  {by/ms/1e6:.0f} GB/s algorithmic  {e/ms/1e6:.2f} Gedges/s")
