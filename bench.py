@@ -60,11 +60,20 @@ def layer_bytes_model(n, e, h, fe, s):
     return e * (16 + 4 * h * s + 3 * fe * s) + n * (12 + 7 * h * s)
 
 
-def kernel_bytes(kind, n_rows, e, h, fe, s):
-    """Compulsory bytes of one launch of this build's two edge kernels."""
-    if kind == "aggregate_fwd":   # col, B[src] row, edge_attr | item record, A row, out row, cnt row (float)
-        return e * (4 + h * s + fe * s) + n_rows * (16 + 2 * h * s + 4 * h)
-    if kind == "aggregate_bwd_src":  # col_t, A[dst] row, G[dst] row, edge_attr | item record, B row, gB row
+def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0):
+    """Compulsory bytes of one launch of this build's two edge kernels.
+
+    aggregate_fwd       per edge: col, B[src] row, edge_attr (+ relu mask words written)
+                        per row:  item record, A row, out row, cnt row (float)
+    aggregate_bwd_src   recomputing form, per edge: col_t, A[dst] row, G[dst] row, edge_attr
+                        mask-bit form,    per edge: col_t, tpos, mask words, G[dst] row, edge_attr
+                        per row:  item record, (B row,) gB row
+    """
+    if kind == "aggregate_fwd":
+        return e * (4 + h * s + fe * s + 4 * mask_words) + n_rows * (16 + 2 * h * s + 4 * h)
+    if kind == "aggregate_bwd_src":
+        if mask_words:
+            return e * (8 + 4 * mask_words + h * s + fe * s) + n_rows * (16 + h * s)
         return e * (4 + 2 * h * s + fe * s) + n_rows * (16 + 2 * h * s)
     raise ValueError(kind)
 
@@ -222,8 +231,10 @@ def main():
         ms = elapsed / args.steps * 1e3
         rows = {"aggregate_fwd": n_rows_fwd, "aggregate_bwd_src": n_rows_bwd}
         per_kernel = {}
+        from mpnn_amd import _lib
+        mask_words = _lib.load().mpnn_mask_words(H, _lib.dtype_code(dtype)) if ops.USE_MASKBITS else 0
         for k, tk in kavg.items():
-            b = kernel_bytes(k, rows[k], e_local, H, Fe, s)
+            b = kernel_bytes(k, rows[k], e_local, H, Fe, s, mask_words)
             per_kernel[k] = {"avg_ms": tk * 1e3, "algorithmic_bytes": b, "GBps": b / tk / 1e9}
         dom = max(kavg, key=kavg.get)
         mp_time = sum(kavg.values())

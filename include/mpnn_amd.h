@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 1
+#define MPNN_ABI_VERSION 2
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -120,6 +120,10 @@ int32_t mpnn_gather_rows(const void* src, const int32_t* index, void* dst, int64
  *           column h (needed by the backward: d out / d A = grad * cnt); may be NULL
  * part_out, part_cnt  float [n_parts, H] scratch for split rows (part_cnt may be NULL
  *           iff cnt is NULL); may be NULL when n_parts == 0
+ * maskbits  optional uint32 [E, mpnn_mask_words(H, dtype)], 16-byte aligned: per CSR position the
+ *           relu mask of the message, one bit per column (word v, bit l <=> column l * words + v),
+ *           consumed by mpnn_aggregate_bwd_src_masked; needs cnt != NULL; pass NULL when
+ *           mpnn_mask_words(H, dtype) == 0 (H too wide or not a multiple of the vector width)
  * Requirements: H % 4 == 0 (f32) or H % 8 == 0 (bf16) for the vector path, otherwise a
  * scalar path is used; base pointers 16-byte aligned and ld* % vector width == 0 for
  * the vector path. 1 <= Fe <= 8.
@@ -129,8 +133,8 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
                            const int32_t* col, const int32_t* items, int64_t n_items,
                            const int32_t* split, int64_t n_split, int64_t n_parts,
                            void* out, int64_t ldo, float* cnt, float* part_out,
-                           float* part_cnt, int64_t num_nodes, int32_t H, int32_t dtype,
-                           mpnn_stream_t stream);
+                           float* part_cnt, uint32_t* maskbits, int64_t num_nodes, int32_t H,
+                           int32_t dtype, mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Backward of the aggregation with respect to B (the per-source table) and We.
@@ -153,6 +157,7 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
  * gwe_scratch  float, at least mpnn_bwd_scratch_floats(H, Fe) elements
  * ------------------------------------------------------------------------- */
 int64_t mpnn_bwd_scratch_floats(int32_t H, int32_t Fe);
+int32_t mpnn_mask_words(int32_t H, int32_t dtype);
 int32_t mpnn_aggregate_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB,
                                const void* G, int64_t ldG, const void* ea_sorted_t,
                                int32_t Fe, const void* We, const int32_t* col_t,
@@ -161,6 +166,21 @@ int32_t mpnn_aggregate_bwd_src(const void* A, int64_t ldA, const void* B, int64_
                                void* gB, int64_t ldgB, void* gWe, float* part_gB,
                                float* gwe_scratch, int64_t num_src_nodes, int32_t H,
                                int32_t dtype, mpnn_stream_t stream);
+
+/* Same gradients from the mask bits the forward stored instead of recomputing the pre-activation:
+ * one row gather per edge (G[dst]) instead of two.
+ *   tpos[p] = position, in the destination-sorted CSR, of the edge at transpose position p
+ *             (tpos = inverse(eid)[eid_t]); maskbits as written by mpnn_aggregate_fwd.
+ *   gB[s, :]  = sum_{p in row s} bits(maskbits[tpos[p]]) * G[col_t[p], :]
+ *   gWe[h, f] = sum_p bit_h(maskbits[tpos[p]]) * G[col_t[p], h] * ea_sorted_t[p, f]
+ */
+int32_t mpnn_aggregate_bwd_src_masked(const void* G, int64_t ldG, const uint32_t* maskbits,
+                                      const int32_t* tpos, const void* ea_sorted_t, int32_t Fe,
+                                      const int32_t* col_t, const int32_t* items_t,
+                                      int64_t n_items_t, const int32_t* split_t, int64_t n_split_t,
+                                      int64_t n_parts_t, void* gB, int64_t ldgB, void* gWe,
+                                      float* part_gB, float* gwe_scratch, int64_t num_src_nodes,
+                                      int32_t H, int32_t dtype, mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * EGNN coordinate update fused into the aggregation pass.

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -30,9 +30,13 @@ SIGNATURES = {
     "mpnn_gather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpnn_aggregate_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
-                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                                     c_void_p]),
+                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                     c_int32, c_void_p]),
     "mpnn_bwd_scratch_floats": (c_int64, [c_int32, c_int32]),
+    "mpnn_mask_words": (c_int32, [c_int32, c_int32]),
+    "mpnn_aggregate_bwd_src_masked": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                                                c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                                c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_aggregate_bwd_src": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                          c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                          c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,

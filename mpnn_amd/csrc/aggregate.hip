@@ -19,6 +19,10 @@
 
 #include "edgeops.h"
 
+#ifndef MPNN_FWD_WAVES
+#define MPNN_FWD_WAVES 4  // minimum waves per SIMD the forward kernel is compiled for (register budget)
+#endif
+
 namespace mpnn {
 
 template <typename T>
@@ -33,11 +37,12 @@ struct FwdArgs {
   float* cnt;
   float* part_out;
   float* part_cnt;
+  uint32_t* maskbits;  // optional [E][VEC] words: bit `lig` of word v = (message column lig*VEC+v of this edge > 0)
   int H; int lpr_log2;
 };
 
 template <typename T, int VEC, int FE, bool RTFE, bool TRAIN, int U>
-__global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
+__global__ void __launch_bounds__(kBlock, MPNN_FWD_WAVES) k_agg_fwd(FwdArgs<T> a) {
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << a.lpr_log2;
   const int lig = lane & (lpr - 1);
@@ -46,6 +51,8 @@ __global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
   const int c0 = blockIdx.y * (lpr * VEC) + lig * VEC;
   const bool act = c0 < a.H;
   const int cc = act ? c0 : 0;  // inactive lanes shadow column 0 and never store
+
+  const int ghalf = (grp << a.lpr_log2) >> 5, gsh = (grp << a.lpr_log2) & 31;
 
   float w[VEC][FE];
   load_edge_weights<T, VEC, FE>(a.We, a.fe, c0, act, w);
@@ -58,9 +65,10 @@ __global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
     int4 it = valid ? a.items[t] : make_int4(0, 0, 0, -1);
     const int row = it.x, e0 = it.y, e1 = it.z;
 
-    float ar[VEC], acc[VEC], cn[VEC];
+    float ar[VEC], acc[VEC];
+    int cn[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { ar[v] = 0.f; acc[v] = 0.f; cn[v] = 0.f; }
+    for (int v = 0; v < VEC; ++v) { ar[v] = 0.f; acc[v] = 0.f; cn[v] = 0; }
     if (valid) RowIO<T, VEC>::load(a.A + (int64_t)row * a.ldA + cc, ar);
 
     int nxt = (e0 + lig < e1) ? a.col[e0 + lig] : 0;
@@ -71,6 +79,7 @@ __global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
       nxt = pn < e1 ? a.col[pn] : 0;
       for (int j = 0; j < nb; j += U) {
         float bv[U][VEC], ev[U][FE];
+        uint32_t bits[U][VEC < 4 ? 4 : VEC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int jj = (j + u) < nb ? (j + u) : (nb - 1);
@@ -88,7 +97,44 @@ __global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
             float m = relu_f((ar[v] + bv[u][v]) + ce[v]);
             m = live ? m : 0.f;
             acc[v] += m;
-            if (TRAIN) cn[v] += (m > 0.f) ? 1.f : 0.f;
+            if (TRAIN) {
+              const bool pos = m > 0.f;
+              cn[v] += pos ? 1 : 0;
+              if (a.maskbits) {
+                // the wave's vote as two 32-bit halves; the group's bits start at bit `gsh` of half `ghalf`
+                const unsigned long long vote = __ballot(pos);
+                bits[u][v] = (ghalf ? (uint32_t)(vote >> 32) : (uint32_t)vote) >> gsh;
+              }
+            }
+          }
+        }
+        if (TRAIN && VEC % 4 == 0 && a.maskbits) {
+          // The group's bits sit at the bottom of each word (higher bits belong to other groups; the reader
+          // tests bit `lig` only).  Lane u of the group stores the words of edge j + u, so the U edges of
+          // this step leave as one contiguous U * VEC * 4 byte store per group.
+          if (lpr >= U) {
+            if (lig < U && (j + lig) < nb) {
+              uint32_t w[VEC];
+#pragma unroll
+              for (int v = 0; v < VEC; ++v) w[v] = bits[0][v];
+#pragma unroll
+              for (int u = 1; u < U; ++u)
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) w[v] = (lig == u) ? bits[u][v] : w[v];
+              uint32_t* mp = a.maskbits + (int64_t)(base + j + lig) * VEC;
+#pragma unroll
+              for (int v = 0; v < VEC; v += 4) *reinterpret_cast<uint4*>(mp + v) = make_uint4(w[v], w[v + 1], w[v + 2], w[v + 3]);
+            }
+          } else if (lig == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if ((j + u) < nb) {
+                uint32_t* mp = a.maskbits + (int64_t)(base + j + u) * VEC;
+#pragma unroll
+                for (int v = 0; v < VEC; v += 4)
+                  *reinterpret_cast<uint4*>(mp + v) = make_uint4(bits[u][v], bits[u][v + 1], bits[u][v + 2], bits[u][v + 3]);
+              }
+            }
           }
         }
       }
@@ -97,7 +143,12 @@ __global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
     if (valid && act) {
       if (it.w < 0) {
         RowIO<T, VEC>::store(a.out + (int64_t)row * a.ldo + c0, acc);
-        if (TRAIN) store_f32<VEC>(a.cnt + (int64_t)row * a.H + c0, cn);
+        if (TRAIN) {
+          float cf[VEC];
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) cf[v] = (float)cn[v];
+          store_f32<VEC>(a.cnt + (int64_t)row * a.H + c0, cf);
+        }
       } else {
         float* po = a.part_out + (int64_t)it.w * a.H + c0;
 #pragma unroll
@@ -105,7 +156,7 @@ __global__ void __launch_bounds__(kBlock) k_agg_fwd(FwdArgs<T> a) {
         if (TRAIN) {
           float* pc = a.part_cnt + (int64_t)it.w * a.H + c0;
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) pc[v] = cn[v];
+          for (int v = 0; v < VEC; ++v) pc[v] = (float)cn[v];
         }
       }
     }
@@ -208,6 +259,106 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src(BwdArgs<T> a) {
     }
   }
 
+  block_reduce_lane_partials<VEC, FE>(gw, lds, a.gwe_partial, a.H, a.fe, a.lpr_log2);
+}
+
+// Backward over the source-sorted transpose using the relu mask bits the forward stored: one row
+// gather per edge (G[dst]) instead of two, no recomputation of the pre-activation.
+//   tpos[p] = position of transposed edge p in the destination-sorted CSR (where its mask words live)
+template <typename T>
+struct BwdMaskArgs {
+  const T* G; int64_t ldG;
+  const uint32_t* maskbits;
+  const int32_t* tpos;
+  const T* ea; int fe;
+  const int32_t* col;
+  const int4* items; int64_t n_items;
+  T* gB; int64_t ldgB;
+  float* part_gB;
+  float* gwe_partial;
+  int H; int lpr_log2;
+};
+
+template <typename T, int VEC, int FE, bool RTFE, int U>
+__global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  const int lpr = 1 << a.lpr_log2;
+  const int lig = lane & (lpr - 1);
+  const int grp = lane >> a.lpr_log2;
+  const int gpw = 64 >> a.lpr_log2;
+  const int c0 = lig * VEC;
+  const bool act = c0 < a.H;
+  const int cc = act ? c0 : 0;
+
+  float gw[VEC][FE];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v)
+#pragma unroll
+    for (int f = 0; f < FE; ++f) gw[v][f] = 0.f;
+
+  const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const int64_t stride = (int64_t)gridDim.x * (kBlock / 64) * gpw;
+  for (int64_t tb = wave * gpw; tb < a.n_items; tb += stride) {
+    const int64_t t = tb + grp;
+    const bool valid = t < a.n_items;
+    int4 it = valid ? a.items[t] : make_int4(0, 0, 0, -1);
+    const int row = it.x, e0 = it.y, e1 = it.z;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+
+    int nxt = 0, nxtp = 0;
+    if (e0 + lig < e1) { nxt = a.col[e0 + lig]; nxtp = a.tpos[e0 + lig]; }
+    for (int base = e0; base < e1; base += lpr) {
+      const int cur = nxt, curp = nxtp;
+      const int nb = (e1 - base) < lpr ? (e1 - base) : lpr;
+      const int pn = base + lpr + lig;
+      nxt = 0; nxtp = 0;
+      if (pn < e1) { nxt = a.col[pn]; nxtp = a.tpos[pn]; }
+      for (int j = 0; j < nb; j += U) {
+        float gv[U][VEC], ev[U][FE];
+        uint32_t mw[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jj = (j + u) < nb ? (j + u) : (nb - 1);
+          const int d = __shfl(cur, jj, lpr);
+          const int pp = __shfl(curp, jj, lpr);
+          RowIO<T, VEC>::load(a.G + (int64_t)d * a.ldG + cc, gv[u]);
+          const uint32_t* mp = a.maskbits + (int64_t)pp * VEC;
+#pragma unroll
+          for (int v = 0; v < VEC; v += 4) {
+            const uint4 w = *reinterpret_cast<const uint4*>(mp + v);
+            mw[u][v] = w.x;
+            if (v + 1 < VEC) mw[u][v + 1] = w.y;
+            if (v + 2 < VEC) mw[u][v + 2] = w.z;
+            if (v + 3 < VEC) mw[u][v + 3] = w.w;
+          }
+          load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(base + jj), a.fe, ev[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool live = (j + u) < nb;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float m = (live && ((mw[u][v] >> lig) & 1u)) ? gv[u][v] : 0.f;
+            acc[v] += m;
+#pragma unroll
+            for (int f = 0; f < FE; ++f) gw[v][f] = fmaf(m, ev[u][f], gw[v][f]);
+          }
+        }
+      }
+    }
+    if (valid && act) {
+      if (it.w < 0) {
+        RowIO<T, VEC>::store(a.gB + (int64_t)row * a.ldgB + c0, acc);
+      } else {
+        float* po = a.part_gB + (int64_t)it.w * a.H + c0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) po[v] = acc[v];
+      }
+    }
+  }
   block_reduce_lane_partials<VEC, FE>(gw, lds, a.gwe_partial, a.H, a.fe, a.lpr_log2);
 }
 
@@ -315,7 +466,7 @@ template <typename T, int VEC>
 static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea, int32_t Fe,
                        const void* We, const int32_t* col, const int32_t* items, int64_t n_items,
                        const int32_t* split, int64_t n_split, void* out, int64_t ldo, float* cnt, float* part_out,
-                       float* part_cnt, int32_t H, const Geometry& g, hipStream_t stream) {
+                       float* part_cnt, uint32_t* maskbits, int32_t H, const Geometry& g, hipStream_t stream) {
   FwdArgs<T> a;
   a.A = static_cast<const T*>(A); a.ldA = ldA;
   a.B = static_cast<const T*>(B); a.ldB = ldB;
@@ -325,6 +476,7 @@ static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, c
   a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
   a.out = static_cast<T*>(out); a.ldo = ldo;
   a.cnt = cnt; a.part_out = part_out; a.part_cnt = part_cnt;
+  a.maskbits = maskbits;
   a.H = H; a.lpr_log2 = g.lpr_log2;
   dim3 grid(row_grid(n_items, g.lpr_log2), g.tiles);
   int32_t rc = cnt ? launch_fwd<T, VEC, true>(a, grid, stream) : launch_fwd<T, VEC, false>(a, grid, stream);
@@ -362,6 +514,38 @@ static int32_t run_bwd(const void* A, int64_t ldA, const void* B, int64_t ldB, c
   else if (Fe == 1) k_agg_bwd_src<T, VEC, 1, false, U><<<grid, kBlock, lds, stream>>>(a);
   else k_agg_bwd_src<T, VEC, kMaxFe, true, U><<<grid, kBlock, lds, stream>>>(a);
   MPNN_LAUNCH_CHECK("k_agg_bwd_src");
+  if (n_split > 0) {
+    int32_t rc = launch_reduce_split<T, VEC>(part_gB, split, n_split, static_cast<T*>(gB), ldgB, H, g, stream);
+    if (rc != MPNN_OK) return rc;
+  }
+  k_reduce_gwe<T><<<H * Fe, kBlock, 0, stream>>>(scratch, (int)grid.x, H * Fe, static_cast<T*>(gWe));
+  MPNN_LAUNCH_CHECK("k_reduce_gwe");
+  return MPNN_OK;
+}
+
+template <typename T, int VEC>
+static int32_t run_bwd_masked(const void* G, int64_t ldG, const uint32_t* maskbits, const int32_t* tpos,
+                              const void* ea, int32_t Fe, const int32_t* col, const int32_t* items, int64_t n_items,
+                              const int32_t* split, int64_t n_split, void* gB, int64_t ldgB, void* gWe,
+                              float* part_gB, float* scratch, int32_t H, const Geometry& g, hipStream_t stream) {
+  constexpr int U = 4;
+  BwdMaskArgs<T> a;
+  a.G = static_cast<const T*>(G); a.ldG = ldG;
+  a.maskbits = maskbits; a.tpos = tpos;
+  a.ea = static_cast<const T*>(ea); a.fe = Fe;
+  a.col = col;
+  a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
+  a.gB = static_cast<T*>(gB); a.ldgB = ldgB;
+  a.part_gB = part_gB; a.gwe_partial = scratch;
+  a.H = H; a.lpr_log2 = g.lpr_log2;
+  dim3 grid(row_grid(n_items, g.lpr_log2), 1);
+  const int tile = (1 << g.lpr_log2) * VEC;
+  const int fe_t = Fe == 4 ? 4 : (Fe == 1 ? 1 : kMaxFe);
+  const size_t lds = (size_t)(kBlock / 64) * tile * fe_t * sizeof(float);
+  if (Fe == 4) k_agg_bwd_src_masked<T, VEC, 4, false, U><<<grid, kBlock, lds, stream>>>(a);
+  else if (Fe == 1) k_agg_bwd_src_masked<T, VEC, 1, false, U><<<grid, kBlock, lds, stream>>>(a);
+  else k_agg_bwd_src_masked<T, VEC, kMaxFe, true, U><<<grid, kBlock, lds, stream>>>(a);
+  MPNN_LAUNCH_CHECK("k_agg_bwd_src_masked");
   if (n_split > 0) {
     int32_t rc = launch_reduce_split<T, VEC>(part_gB, split, n_split, static_cast<T*>(gB), ldgB, H, g, stream);
     if (rc != MPNN_OK) return rc;
@@ -415,8 +599,8 @@ extern "C" {
 int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea_sorted, int32_t Fe,
                            const void* We, const int32_t* col, const int32_t* items, int64_t n_items,
                            const int32_t* split, int64_t n_split, int64_t n_parts, void* out, int64_t ldo, float* cnt,
-                           float* part_out, float* part_cnt, int64_t num_nodes, int32_t H, int32_t dtype,
-                           mpnn_stream_t stream) {
+                           float* part_out, float* part_cnt, uint32_t* maskbits, int64_t num_nodes, int32_t H,
+                           int32_t dtype, mpnn_stream_t stream) {
   if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: dtype %d", dtype);
   if (H < 1 || Fe < 1 || Fe > kMaxFe)
     return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: H=%d (>=1), Fe=%d (1..%d)", H, Fe, kMaxFe);
@@ -433,18 +617,27 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
   const bool vec_ok = aligned16(A) && aligned16(B) && aligned16(out) && aligned16(cnt) && aligned16(ea_sorted) &&
                       ldA % full == 0 && ldB % full == 0 && ldo % full == 0;
   const Geometry g = geometry(H, dtype, vec_ok);
+  if (maskbits && (!cnt || g.vec == 1 || g.tiles != 1 || g.lpr_log2 > 5 || ((uintptr_t)maskbits & 15)))
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: maskbits needs cnt, the vector path and mpnn_mask_words(H, dtype) > 0");
   if (dtype == MPNN_F32) {
     if (g.vec == 4)
       return run_fwd<float, 4>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                               part_out, part_cnt, H, g, stream);
+                               part_out, part_cnt, maskbits, H, g, stream);
     return run_fwd<float, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                             part_out, part_cnt, H, g, stream);
+                             part_out, part_cnt, maskbits, H, g, stream);
   }
   if (g.vec == 8)
     return run_fwd<bf16_t, 8>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                              part_out, part_cnt, H, g, stream);
+                              part_out, part_cnt, maskbits, H, g, stream);
   return run_fwd<bf16_t, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                            part_out, part_cnt, H, g, stream);
+                            part_out, part_cnt, maskbits, H, g, stream);
+}
+
+int32_t mpnn_mask_words(int32_t H, int32_t dtype) {
+  if (H < 1 || (dtype != MPNN_F32 && dtype != MPNN_BF16)) return 0;
+  const Geometry g = geometry(H, dtype, true);
+  if (g.vec == 1 || g.tiles != 1 || g.lpr_log2 > 5) return 0;
+  return g.vec;
 }
 
 int64_t mpnn_bwd_scratch_floats(int32_t H, int32_t Fe) {
@@ -492,6 +685,38 @@ int32_t mpnn_aggregate_bwd_src(const void* A, int64_t ldA, const void* B, int64_
                               n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
   return run_bwd<bf16_t, 1>(A, ldA, B, ldB, G, ldG, ea_sorted_t, Fe, We, col_t, items_t, n_items_t, split_t,
                             n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
+}
+
+int32_t mpnn_aggregate_bwd_src_masked(const void* G, int64_t ldG, const uint32_t* maskbits, const int32_t* tpos,
+                                      const void* ea_sorted_t, int32_t Fe, const int32_t* col_t,
+                                      const int32_t* items_t, int64_t n_items_t, const int32_t* split_t,
+                                      int64_t n_split_t, int64_t n_parts_t, void* gB, int64_t ldgB, void* gWe,
+                                      float* part_gB, float* gwe_scratch, int64_t num_src_nodes, int32_t H,
+                                      int32_t dtype, mpnn_stream_t stream) {
+  const char* who = "mpnn_aggregate_bwd_src_masked";
+  if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "%s: dtype %d", who, dtype);
+  if (H < 1 || Fe < 1 || Fe > kMaxFe) return fail(MPNN_E_INVALID, "%s: H=%d (>=1), Fe=%d (1..%d)", who, H, Fe, kMaxFe);
+  if (num_src_nodes < 0 || n_items_t < 0 || n_split_t < 0 || n_parts_t < 0)
+    return fail(MPNN_E_INVALID, "%s: negative size", who);
+  if (!gWe || !gwe_scratch) return fail(MPNN_E_INVALID, "%s: gWe/gwe_scratch is null", who);
+  if (mpnn_mask_words(H, dtype) == 0) return fail(MPNN_E_INVALID, "%s: H=%d has no mask-bit layout", who, H);
+  if (num_src_nodes == 0 || n_items_t == 0) {
+    MPNN_HIP_CHECK(hipMemsetAsync(gWe, 0, (size_t)H * Fe * (dtype == MPNN_BF16 ? 2 : 4), stream));
+    return MPNN_OK;
+  }
+  if (!G || !maskbits || !tpos || !items_t || !gB) return fail(MPNN_E_INVALID, "%s: null pointer argument", who);
+  if (ldG < H || ldgB < H) return fail(MPNN_E_INVALID, "%s: leading dimension below H", who);
+  if (n_parts_t > 0 && (!part_gB || !split_t)) return fail(MPNN_E_INVALID, "%s: split rows present but scratch slab is null", who);
+  const int full = dtype == MPNN_BF16 ? 8 : 4;
+  if (!aligned16(G) || !aligned16(gB) || !aligned16(ea_sorted_t) || !aligned16(maskbits) || !aligned16(items_t) ||
+      !aligned16(split_t) || ldG % full != 0 || ldgB % full != 0)
+    return fail(MPNN_E_INVALID, "%s: operands must be 16-byte aligned with ld %% %d == 0", who, full);
+  const Geometry g = geometry(H, dtype, true);
+  if (dtype == MPNN_F32)
+    return run_bwd_masked<float, 4>(G, ldG, maskbits, tpos, ea_sorted_t, Fe, col_t, items_t, n_items_t, split_t,
+                                    n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
+  return run_bwd_masked<bf16_t, 8>(G, ldG, maskbits, tpos, ea_sorted_t, Fe, col_t, items_t, n_items_t, split_t,
+                                   n_split_t, gB, ldgB, gWe, part_gB, gwe_scratch, H, g, stream);
 }
 
 int32_t mpnn_segment_mean_fwd(const void* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, void* out,

@@ -96,6 +96,17 @@ class MPGraph:
         self._ea_key = None
         self._ea_sorted = None
         self._scratch = {}
+        self._tpos = None
+
+    @property
+    def tpos(self) -> torch.Tensor:
+        """tpos[p] = position in the destination-sorted CSR of the edge at transpose position p."""
+        if self._tpos is None:
+            e = self.num_edges
+            inv = torch.empty(e, dtype=torch.int32, device=self.by_dst.eid.device)
+            inv[self.by_dst.eid.long()] = torch.arange(e, dtype=torch.int32, device=inv.device)
+            self._tpos = inv[self.by_src.eid.long()].contiguous()
+        return self._tpos
 
     def sorted_edge_attr(self, edge_attr: torch.Tensor, dtype: torch.dtype):
         """edge_attr laid out in CSR order and in transpose order (cached per tensor version)."""

@@ -7,6 +7,8 @@ backward autograd derives for it; ``segment_mean`` replaces ``global_mean_pool``
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -44,12 +46,22 @@ def _check_features(name, t, rows, H=None):
         raise ValueError(f"{name} must have unit stride along features, got strides {t.stride()}")
 
 
+# The backward reads the relu mask bits the forward stored (one row gather per edge) when the layout exists
+# for H; MPNN_NO_MASKBITS=1 forces the recomputing backward (two row gathers per edge, no [E, words] buffer).
+USE_MASKBITS = os.environ.get("MPNN_NO_MASKBITS", "0") != "1"
+
+
 def _run_forward(A, B, ea_sorted, We, csr: CSR, graph: MPGraph, want_cnt: bool):
     lib = _lib.load()
     N, H = A.shape
     dev, dtype = A.device, A.dtype
     out = torch.empty((N, H), dtype=dtype, device=dev)
     cnt = torch.empty((N, H), dtype=torch.float32, device=dev) if want_cnt else None
+    words = lib.mpnn_mask_words(H, _lib.dtype_code(dtype)) if (want_cnt and USE_MASKBITS and csr.num_edges) else 0
+    vec = 8 if dtype == torch.bfloat16 else 4
+    if words and (A.data_ptr() % 16 or B.data_ptr() % 16 or A.stride(0) % vec or B.stride(0) % vec):
+        words = 0  # the library would take its scalar path, which writes no mask bits
+    maskbits = torch.empty((csr.num_edges, words), dtype=torch.int32, device=dev) if words else None
     part_out = part_cnt = None
     if csr.n_parts > 0:
         part_out = graph.scratch("part_out", (csr.n_parts, H), torch.float32, dev)
@@ -59,12 +71,12 @@ def _run_forward(A, B, ea_sorted, We, csr: CSR, graph: MPGraph, want_cnt: bool):
         _lib.check(lib.mpnn_aggregate_fwd(
             _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(ea_sorted), ea_sorted.size(1), _lib.ptr(We),
             _lib.ptr(csr.col), _lib.ptr(csr.items), csr.n_items, _lib.ptr(csr.split), csr.n_split, csr.n_parts,
-            _lib.ptr(out), out.stride(0), _lib.ptr(cnt), _lib.ptr(part_out), _lib.ptr(part_cnt), N, H,
-            _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_fwd")
-    return out, cnt
+            _lib.ptr(out), out.stride(0), _lib.ptr(cnt), _lib.ptr(part_out), _lib.ptr(part_cnt), _lib.ptr(maskbits),
+            N, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_fwd")
+    return out, cnt, maskbits
 
 
-def _run_backward_src(A, B, G, ea_sorted_t, We, csr_t: CSR, graph: MPGraph, gB):
+def _run_backward_src(A, B, G, ea_sorted_t, We, csr_t: CSR, graph: MPGraph, gB, maskbits=None):
     """Fills gB (a [Ns, H] view, unit feature stride) and returns gWe."""
     lib = _lib.load()
     H = A.size(1)
@@ -73,6 +85,15 @@ def _run_backward_src(A, B, G, ea_sorted_t, We, csr_t: CSR, graph: MPGraph, gB):
     gWe = torch.empty((H, Fe), dtype=dtype, device=dev)
     part = graph.scratch("part_gB", (csr_t.n_parts, H), torch.float32, dev) if csr_t.n_parts > 0 else None
     scratch = graph.scratch("gwe", (lib.mpnn_bwd_scratch_floats(H, Fe),), torch.float32, dev)
+    if maskbits is not None:
+        with _Timed("aggregate_bwd_src", dev):
+            _lib.check(lib.mpnn_aggregate_bwd_src_masked(
+                _lib.ptr(G), G.stride(0), _lib.ptr(maskbits), _lib.ptr(graph.tpos), _lib.ptr(ea_sorted_t), Fe,
+                _lib.ptr(csr_t.col), _lib.ptr(csr_t.items), csr_t.n_items, _lib.ptr(csr_t.split), csr_t.n_split,
+                csr_t.n_parts, _lib.ptr(gB), gB.stride(0), _lib.ptr(gWe), _lib.ptr(part), _lib.ptr(scratch),
+                csr_t.num_rows, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)),
+                "mpnn_aggregate_bwd_src_masked")
+        return gWe
     with _Timed("aggregate_bwd_src", dev):
         _lib.check(lib.mpnn_aggregate_bwd_src(
             _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(G), G.stride(0), _lib.ptr(ea_sorted_t), Fe,
@@ -106,21 +127,23 @@ class _AggregateFused(torch.autograd.Function):
         ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
         We_c = We.contiguous()
         want = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
-        out, cnt = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
+        out, cnt, maskbits = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
         if want:
-            ctx.save_for_backward(AB, We_c, cnt, ea_t)
+            if maskbits is not None:
+                graph.tpos  # built once per graph, outside the backward
+            ctx.save_for_backward(AB, We_c, cnt, ea_t, maskbits)
             ctx.graph = graph
         return out
 
     @staticmethod
     def backward(ctx, g):
-        AB, We, cnt, ea_t = ctx.saved_tensors
+        AB, We, cnt, ea_t, maskbits = ctx.saved_tensors
         graph = ctx.graph
         H = AB.size(1) // 2
         g = g.contiguous()
         gAB = torch.empty_like(AB)
         torch.mul(g, cnt, out=gAB[:, :H])  # d out / d A: every edge of row n sees A[n]
-        gWe = _run_backward_src(AB[:, :H], AB[:, H:], g, ea_t, We, graph.by_src, graph, gAB[:, H:])
+        gWe = _run_backward_src(AB[:, :H], AB[:, H:], g, ea_t, We, graph.by_src, graph, gAB[:, H:], maskbits)
         return gAB, None, gWe, None
 
 
@@ -132,20 +155,22 @@ class _Aggregate(torch.autograd.Function):
         ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
         We_c = We.contiguous()
         want = any(ctx.needs_input_grad[i] for i in (0, 1, 3))
-        out, cnt = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
+        out, cnt, maskbits = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
         if want:
-            ctx.save_for_backward(A, B, We_c, cnt, ea_t)
+            if maskbits is not None:
+                graph.tpos
+            ctx.save_for_backward(A, B, We_c, cnt, ea_t, maskbits)
             ctx.graph = graph
         return out
 
     @staticmethod
     def backward(ctx, g):
-        A, B, We, cnt, ea_t = ctx.saved_tensors
+        A, B, We, cnt, ea_t, maskbits = ctx.saved_tensors
         graph = ctx.graph
         g = g.contiguous()
         gA = (g * cnt).to(A.dtype)
         gB = torch.empty((graph.num_src, A.size(1)), dtype=A.dtype, device=A.device)
-        gWe = _run_backward_src(A, B, g, ea_t, We, graph.by_src, graph, gB)
+        gWe = _run_backward_src(A, B, g, ea_t, We, graph.by_src, graph, gB, maskbits)
         return gA, gB, None, gWe, None
 
 

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_header_compiles_as_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "mpnn_amd.h"\nint main(void){return MPNN_ABI_VERSION == 1 ? 0 : 1;}\n')
+    src.write_text('#include "mpnn_amd.h"\nint main(void){return MPNN_ABI_VERSION == 2 ? 0 : 1;}\n')
     rc = os.system(f"gcc -std=c99 -Wall -Werror -I{ROOT}/include -c {src} -o {tmp_path}/t.o")
     assert rc == 0
 
@@ -41,19 +41,21 @@ def test_argument_validation_reports_errors_without_a_gpu():
     lib = _lib.load()
     # bad dtype / bad sizes are rejected before any HIP call
     rc = lib.mpnn_aggregate_fwd(None, 0, None, 0, None, 4, None, None, None, 1, None, 0, 0, None, 0, None, None,
-                                None, 1, 64, 7, None)
+                                None, None, 1, 64, 7, None)
     assert rc == -1 and b"dtype" in lib.mpnn_last_error()
     rc = lib.mpnn_aggregate_fwd(None, 0, None, 0, None, 99, None, None, None, 1, None, 0, 0, None, 0, None, None,
-                                None, 1, 64, 0, None)
+                                None, None, 1, 64, 0, None)
     assert rc == -1 and b"Fe" in lib.mpnn_last_error()
     rc = lib.mpnn_aggregate_fwd(None, 64, None, 64, None, 4, None, None, None, 1, None, 0, 0, None, 64, None, None,
-                                None, 1, 64, 0, None)
+                                None, None, 1, 64, 0, None)
     assert rc == -1 and b"null" in lib.mpnn_last_error()
     rc = lib.mpnn_gather_rows(None, None, None, 4, 3, None)
     assert rc == -1
     rc = lib.mpnn_csr_build(None, None, -1, 4, 4, None, None, None, None, None, 0, None)
     assert rc == -1
     assert lib.mpnn_bwd_scratch_floats(64, 4) == 2048 * 64 * 4
+    assert lib.mpnn_mask_words(128, 0) == 4 and lib.mpnn_mask_words(64, 1) == 8
+    assert lib.mpnn_mask_words(7, 0) == 0 and lib.mpnn_mask_words(256, 0) == 0
     with pytest.raises(_lib.MpnnError):
         _lib.check(rc, "mpnn_csr_build")
 

@@ -360,3 +360,16 @@ def test_gemm_tn(n, m, k, dev):
     assert float(wide[:, :5].abs().sum()) == 0.0
     again = gemm_tn(g.to(dev), x.to(dev), mask=mask.to(dev))
     assert torch.equal(again, got.contiguous()), "weight gradient is not bitwise reproducible"
+
+
+def test_recomputing_backward_matches_mask_bit_backward(dev):
+    """The two backward forms (stored relu mask bits vs. recomputed pre-activation) give the same gradients bit for bit."""
+    from mpnn_amd import ops
+    a, _, _ = _aggregate_case(dev, 400, 20000, 128, 4, seed=9, skew=True)
+    ops.USE_MASKBITS = False
+    try:
+        b, _, _ = _aggregate_case(dev, 400, 20000, 128, 4, seed=9, skew=True)
+    finally:
+        ops.USE_MASKBITS = True
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)

@@ -38,3 +38,13 @@ for k, v in t.items():
     else:
         by = e * (4 + 2 * H * s + 4 * s) + n * (16 + 2 * H * s)
     print(f"{kind} scale={scale} H={H} U={os.environ.get('MPNN_FWD_U','4')} {k}: {ms:.3f} ms  {by/ms/1e6:.0f} GB/s algorithmic  {e/ms/1e6:.2f} Gedges/s")
+# inference-mode forward (no cnt / mask outputs)
+with torch.no_grad():
+    ops.EVENT_SINK = []
+    for _ in range(5):
+        aggregate_fused(ab.detach(), d["edge_attr"], we.detach(), g)
+    torch.cuda.synchronize()
+    ev = ops.EVENT_SINK; ops.EVENT_SINK = None
+ms = sorted(a.elapsed_time(b) for _, a, b in ev)[len(ev) // 2]
+by = e * (4 + H * s + 4 * s) + n * (16 + 2 * H * s)
+print(f"{kind} scale={scale} H={H} inference fwd: {ms:.3f} ms  {by/ms/1e6:.0f} GB/s algorithmic")
