@@ -236,6 +236,8 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
  *   The second term is skipped when K2 == 0.  maskI (optional, same shape as XI): XI is read as
  *   XI * (maskI > 0) -- the relu backward fused into the operand load.  With a pre-transposed weight the
  *   same entry point computes input gradients (dX = G W  ==  G (W^T)^T).
+ *   Y2 (optional, with emul [N,M]): second output Y2 = Y * emul written by the same epilogue
+ *   (d aggr and d A = d aggr * cnt leave one GEMM together).
  * mpnn_gemm_tn_f32:  dW[M,K] = (G * (mask > 0))[N,M]^T X[N,K]  (weight gradient; rows are summed in a fixed
  *   order through `scratch`, float, at least mpnn_gemm_tn_scratch_floats(N, M, K) elements).
  * All matrices row-major with leading dimensions in elements.
@@ -243,8 +245,8 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
 int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int64_t ldm1,
                          const float* W1, int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2,
                          const float* mask2, int64_t ldm2, const float* W2, int64_t ldw2, int32_t K2,
-                         float* Y, int64_t ldy, int64_t N, int32_t M, int32_t relu,
-                         mpnn_stream_t stream);
+                         float* Y, int64_t ldy, const float* emul, int64_t ldemul, float* Y2,
+                         int64_t ldy2, int64_t N, int32_t M, int32_t relu, mpnn_stream_t stream);
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K);
 int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm,
                          const float* X, int64_t ldx, float* dW, int64_t lddw, float* scratch,

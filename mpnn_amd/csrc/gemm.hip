@@ -36,6 +36,8 @@ struct NtArgs {
   NtSegment seg[2];
   int nseg;
   float* Y; int64_t ldy;
+  const float* emul; int64_t ldemul;  // optional [N, M]: second output Y2 = Y * emul
+  float* Y2; int64_t ldy2;
   int64_t N; int M;
   int relu;
 };
@@ -192,6 +194,7 @@ __global__ void __launch_bounds__(kBlock * WC) k_gemm_nt(NtArgs a) {
             float v = acc[t][r];
             if (a.relu) v = v <= 0.f ? 0.f : v;
             a.Y[row * a.ldy + col] = v;
+            if (a.Y2) a.Y2[row * a.ldy2 + col] = v * a.emul[row * a.ldemul + col];
           }
           acc[t][r] = 0.f;
         }
@@ -301,14 +304,26 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
     }
 }
 
-// dW[m, k] = sum over slabs b (ascending) of partial[b][m][k]
+// dW[m, k] = sum over slabs of partial[b][m][k] in a fixed order: each wave of a block takes the slabs
+// b = wave, wave + 4, ... (ascending) for 64 consecutive outputs, then the four wave sums are added in wave order.
 __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int nslabs, int M, int K,
                                                          float* __restrict__ dW, int64_t ldw) {
+  __shared__ float red[kBlock];
   const int64_t count = (int64_t)M * K;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock) {
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < count; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + o;
     float s = 0.f;
-    for (int b = 0; b < nslabs; ++b) s += partial[(int64_t)b * count + i];
-    dW[(i / K) * ldw + (i % K)] = s;
+    if (i < count)
+      for (int b = g; b < nslabs; b += kBlock / 64) s += partial[(int64_t)b * count + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < count) {
+      float tot = red[o];
+      for (int k = 1; k < kBlock / 64; ++k) tot += red[k * 64 + o];
+      dW[(i / K) * ldw + (i % K)] = tot;
+    }
+    __syncthreads();
   }
 }
 
@@ -349,8 +364,9 @@ extern "C" {
 
 int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int64_t ldm1, const float* W1,
                          int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2, const float* mask2, int64_t ldm2,
-                         const float* W2, int64_t ldw2, int32_t K2, float* Y, int64_t ldy, int64_t N, int32_t M,
-                         int32_t relu, mpnn_stream_t stream) {
+                         const float* W2, int64_t ldw2, int32_t K2, float* Y, int64_t ldy, const float* emul,
+                         int64_t ldemul, float* Y2, int64_t ldy2, int64_t N, int32_t M, int32_t relu,
+                         mpnn_stream_t stream) {
   if (N < 0 || M < 1 || K1 < 1 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: bad sizes");
   if (N == 0) return MPNN_OK;
   if (!X1 || !W1 || !Y || (K2 > 0 && (!X2 || !W2))) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: null pointer argument");
@@ -360,7 +376,9 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
   a.seg[0] = NtSegment{X1, ldx1, mask1, ldm1, W1, ldw1, K1};
   a.seg[1] = NtSegment{X2, ldx2, mask2, ldm2, W2, ldw2, K2};
   a.nseg = K2 > 0 ? 2 : 1;
-  a.Y = Y; a.ldy = ldy; a.N = N; a.M = M; a.relu = relu;
+  if (Y2 && (!emul || ldemul < M || ldy2 < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: Y2 needs emul and ld >= M");
+  a.Y = Y; a.ldy = ldy; a.emul = emul; a.ldemul = ldemul; a.Y2 = Y2; a.ldy2 = ldy2;
+  a.N = N; a.M = M; a.relu = relu;
   const bool aligned = nt_aligned(a);
   if (M <= 32) launch_nt<1, 1>(a, aligned, stream);
   else if (M <= 64) launch_nt<2, 1>(a, aligned, stream);
@@ -395,7 +413,7 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
   if (aligned) k_gemm_tn<true><<<grid, kBlock, 0, stream>>>(a);
   else k_gemm_tn<false><<<grid, kBlock, 0, stream>>>(a);
   MPNN_LAUNCH_CHECK("k_gemm_tn");
-  int64_t blocks = ((int64_t)M * K + kBlock - 1) / kBlock;
+  int64_t blocks = ((int64_t)M * K + 63) / 64;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
   k_sum_partials<<<(int)blocks, kBlock, 0, stream>>>(scratch, slabs, M, K, dW, lddw);
   MPNN_LAUNCH_CHECK("k_sum_partials");

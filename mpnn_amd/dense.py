@@ -29,8 +29,11 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()
 
 
-def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False) -> torch.Tensor:
-    """act(x1 @ w1^T [+ x2 @ w2^T]); maskI > 0 selects the entries of xI that are used."""
+def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=None, out2=None) -> torch.Tensor:
+    """act(x1 @ w1^T [+ x2 @ w2^T]); maskI > 0 selects the entries of xI that are used.
+
+    With ``emul`` [N, M] and ``out2`` (a [N, M] view with unit column stride) the epilogue also writes
+    out2 = result * emul."""
     lib = _lib.load()
     x1, w1 = _rows(x1), _rows(w1)
     n, k1 = x1.shape
@@ -46,7 +49,9 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False) -> tor
         _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(mask2),
         mask2.stride(0) if mask2 is not None else 0, _lib.ptr(w2), w2.stride(0) if w2 is not None else 0,
         x2.size(1) if x2 is not None else 0,
-        _lib.ptr(y), y.stride(0), n, m, 1 if relu else 0, _lib.stream_handle(x1.device)), "mpnn_gemm_nt_f32")
+        _lib.ptr(y), y.stride(0), _lib.ptr(emul), emul.stride(0) if emul is not None else 0, _lib.ptr(out2),
+        out2.stride(0) if out2 is not None else 0, n, m, 1 if relu else 0, _lib.stream_handle(x1.device)),
+        "mpnn_gemm_nt_f32")
     return y
 
 

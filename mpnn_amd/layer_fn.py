@@ -1,0 +1,72 @@
+"""One autograd node for a whole MPNN layer (float32, GPU).
+
+Forward and backward of MPNNLayerSum / MPNNLayerCat (reference models/layers.py:25-69 and :91-140) as a fixed
+sequence of library calls, so that nothing between them needs an elementwise pass:
+
+  forward    AB   = x Wn^T                                  NT GEMM        (Wn = fused_linear, or [Wi ; Wj] of `linear`)
+             aggr = AGG(AB[:, :H], AB[:, H:], e, We)        edge pass      (+ cnt, relu mask bits)
+             y    = relu(x Wx^T + aggr Wa^T)                NT GEMM, 2 segments, relu in the epilogue
+  backward   ga   = (gy * [y>0]) Wa ;  gAB[:, :H] = ga*cnt  NT GEMM, relu mask on the operand, * cnt in the epilogue
+             gAB[:, H:], gWe = edge backward(ga)            edge pass over the transpose
+             gx   = (gy * [y>0]) Wx + gAB Wn                NT GEMM, 2 segments (no separate add)
+             gWn  = gAB^T x ; gW_out = (gy*[y>0])^T [x | aggr]   TN GEMMs
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .dense import gemm_nt, gemm_tn
+from .graph import MPGraph
+
+
+class _LayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
+        x = x if x.is_contiguous() else x.contiguous()
+        f = x.size(1)
+        h = w_out.size(0)
+        ab = gemm_nt(x, w_nodes)
+        a, b = ab[:, :h], ab[:, h:]
+        ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
+        w_edge_c = w_edge.contiguous()
+        want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
+        aggr, cnt, maskbits = ops._run_forward(a, b, ea_s, w_edge_c, graph.by_dst, graph, want)
+        y = gemm_nt(x, w_out[:, :f], aggr, w_out[:, f:], relu=True)
+        if want:
+            if maskbits is not None:
+                graph.tpos
+            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge_c, w_out)
+            ctx.graph = graph
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
+        graph = ctx.graph
+        f = x.size(1)
+        h = w_out.size(0)
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        wt_out = w_out.t().contiguous()               # [F+H, H]
+        g_ab = torch.empty_like(ab)
+        ga = gemm_nt(gy, wt_out[f:], mask1=y, emul=cnt, out2=g_ab[:, :h])
+        g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_nt(gy, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=y)
+        g_wn = gemm_tn(g_ab, x) if ctx.needs_input_grad[2] else None
+        g_wout = None
+        if ctx.needs_input_grad[4]:
+            g_wout = torch.empty_like(w_out)
+            gemm_tn(gy, x, mask=y, out=g_wout[:, :f])
+            gemm_tn(gy, aggr, mask=y, out=g_wout[:, f:])
+        return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
+
+
+def supported(x, edge_attr, *weights) -> bool:
+    return x.is_cuda and all(t.dtype == torch.float32 for t in (x, edge_attr) + weights)
+
+
+@torch.compiler.disable
+def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph) -> torch.Tensor:
+    return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)

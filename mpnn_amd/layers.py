@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import Linear
 
-from . import dense
+from . import dense, layer_fn
 from .graph import graph_for
 from .ops import aggregate_fused, egnn_aggregate
 
@@ -41,6 +41,8 @@ class MPNNLayerCat(torch.nn.Module):
         graph = graph_for(edge_index, x.size(0))
         # [Wi ; Wj] stacked row-wise gives the [N, 2H] table (target half, source half) in one GEMM.
         w_nodes = torch.cat([w[:, :f], w[:, f:2 * f]], dim=0)
+        if layer_fn.supported(x, edge_attr, w, self.linear_out.weight):
+            return layer_fn.layer_forward(x, edge_attr, w_nodes, w[:, 2 * f:], self.linear_out.weight, graph)
         ab = dense.project(x, w_nodes)
         aggr = aggregate_fused(ab, edge_attr, w[:, 2 * f:], graph)
         return _update(x, aggr, self.linear_out.weight)
@@ -56,6 +58,9 @@ class MPNNLayerSum(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         graph = graph_for(edge_index, x.size(0))
+        if layer_fn.supported(x, edge_attr, self.fused_linear.weight, self.linear_3.weight, self.linear_out.weight):
+            return layer_fn.layer_forward(x, edge_attr, self.fused_linear.weight, self.linear_3.weight,
+                                          self.linear_out.weight, graph)
         ab = dense.project(x, self.fused_linear.weight)  # xs = ab[:, :H] (target), xt = ab[:, H:] (source)
         aggr = aggregate_fused(ab, edge_attr, self.linear_3.weight, graph)
         return _update(x, aggr, self.linear_out.weight)
