@@ -327,13 +327,16 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict
   }
 }
 
+// Number of row-slab walkers (gridDim.x) of the TN kernel: enough blocks to fill the chip (two 64 KiB-LDS
+// blocks per CU over all output tiles), but at least 8 slabs of 32 rows per walker so that the partial tiles
+// written and re-read stay small next to the operands.
 static int tn_slabs(int64_t N, int M, int K) {
   const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
-  int slabs = 512 / tiles;  // two resident blocks (64 KiB of LDS each) per CU in total
+  int64_t slabs = 512 / tiles;
+  const int64_t need = ((N + 31) / 32 + 7) / 8;
+  if (slabs > need) slabs = need;
   if (slabs < 1) slabs = 1;
-  const int64_t need = (N + 31) / 32;
-  if (slabs > need) slabs = (int)(need < 1 ? 1 : need);
-  return slabs;
+  return (int)slabs;
 }
 
 static bool nt_aligned(const NtArgs& a) {
