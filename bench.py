@@ -78,6 +78,24 @@ def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0):
     raise ValueError(kind)
 
 
+def pmc_traffic(workload, dtype, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
+    runs of this script, corrected for gfx950 as profiles/*_pmc_traffic.json records), or None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as fh:
+                rec = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if rec.get("dtype") != dtype:
+            continue
+        for v in rec.get("kernels", {}).get(workload, {}).values():
+            if v.get("bench_kernel") == kernel:
+                return v["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(name, mode, target_seconds=20.0):
     """CPU oracle (plain torch ops, the arithmetic the reference runs through PyG) on a bounded sample."""
     from oracle import reference_oracle as O
@@ -288,7 +306,9 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world} + halo all-gather",
                        "launch": "HIP graph replay" if run_step is not step else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None},
+                         "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.workload, args.dtype, dom) if (world == 1 and args.scale == 1.0
+                                                                                     and args.mode == "sum") else None},
             "kernels": per_kernel,
             "message_passing_only": {
                 "ms": mp_time * 1e3, "edges_per_sec": e_local / mp_time,
