@@ -31,9 +31,13 @@ def load_golden(name):
         return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
 
 
-def assert_close(got, want, rtol, atol_scale=1.0, what=""):
+def assert_close(got, want, rtol, atol_scale=1.0, what="", kink_frac=0.0):
     """|got - want| <= atol + rtol*|want| with atol = rtol * atol_scale * max|want| (outputs pass through relu
-    with no bias, so many entries are exactly or nearly zero and a purely relative test is meaningless there)."""
+    with no bias, so many entries are exactly or nearly zero and a purely relative test is meaningless there).
+
+    kink_frac: fraction of entries allowed outside the bound.  Two correct float32 evaluations of a relu network
+    can disagree on the sign of a pre-activation that is zero to rounding; the gradient then differs by one whole
+    term there.  Only the multi-million-entry full-size comparisons use a non-zero value (1e-5)."""
     got = got.detach().double().cpu()
     want = want.detach().double().cpu()
     assert got.shape == want.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
@@ -42,7 +46,7 @@ def assert_close(got, want, rtol, atol_scale=1.0, what=""):
     err = (got - want).abs()
     bound = atol + rtol * want.abs()
     bad = err > bound
-    if bad.any():
+    if bad.any() and int(bad.sum()) > kink_frac * bad.numel():
         i = int(torch.argmax(err - bound))
         raise AssertionError(
             f"{what}: {int(bad.sum())}/{bad.numel()} outside rtol={rtol} atol={atol:.3e}; worst "
