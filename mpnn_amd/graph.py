@@ -62,13 +62,24 @@ def _build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: 
     _lib.check(lib.mpnn_items_build(_lib.ptr(csr.rowptr), num_rows, chunk, max_parts, _lib.ptr(csr.items),
                                     items_cap, _lib.ptr(csr.split), split_cap, _lib.ptr(meta), _lib.ptr(ws),
                                     ws.numel(), stream), "mpnn_items_build")
-    # One host read per graph build: item counts and the range-check flag.
-    host = torch.cat([meta[:4], status[:1]]).tolist()
-    if host[4] != 0:
-        raise IndexError(f"edge_index holds node ids outside [0, {num_rows}) x [0, {num_cols})")
-    if host[3] != 0:
-        raise _lib.MpnnError("mpnn_items_build overflowed its output capacity")
-    csr.n_items, csr.n_parts, csr.n_split = host[0], host[1], host[2]
+    return csr, torch.cat([meta[:4], status[:1]])
+
+
+def _finish(csrs, pending) -> None:
+    """One host read for all CSRs built together: item counts, overflow flag, range-check flag."""
+    host = torch.stack(pending).tolist()
+    for csr, h in zip(csrs, host):
+        if h[4] != 0:
+            raise IndexError(f"edge_index holds node ids outside [0, {csr.num_rows}) x [0, {csr.num_cols})")
+        if h[3] != 0:
+            raise _lib.MpnnError("mpnn_items_build overflowed its output capacity")
+        csr.n_items, csr.n_parts, csr.n_split = h[0], h[1], h[2]
+
+
+def build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: int,
+              chunk: int = CHUNK, max_parts: int = MAX_PARTS) -> CSR:
+    csr, pending = _build_csr(key, other, num_rows, num_cols, chunk, max_parts)
+    _finish([csr], [pending])
     return csr
 
 
@@ -91,8 +102,9 @@ class MPGraph:
         src = edge_index[0].contiguous()
         dst = edge_index[1].contiguous()
         self.num_dst, self.num_src, self.num_edges = int(num_dst), int(num_src), src.numel()
-        self.by_dst = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts)
-        self.by_src = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts)
+        self.by_dst, p1 = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts)
+        self.by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts)
+        _finish([self.by_dst, self.by_src], [p1, p2])
         self._ea_key = None
         self._ea_sorted = None
         self._scratch = {}

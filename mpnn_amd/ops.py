@@ -12,7 +12,7 @@ import os
 import torch
 
 from . import _lib
-from .graph import CSR, MPGraph, _build_csr, CHUNK, MAX_PARTS
+from .graph import CSR, MPGraph, build_csr
 
 
 # Optional timing hook: when set to a list, every library call of the two edge passes appends
@@ -333,7 +333,7 @@ def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: int | None = No
         if size is None:
             size = int(batch.max().item()) + 1 if batch.numel() > 0 else 0  # host read, as in the reference
         nodes = torch.arange(batch.numel(), dtype=torch.int64, device=batch.device)
-        csr = _build_csr(batch.contiguous(), nodes, size, batch.numel(), CHUNK, MAX_PARTS)
+        csr = build_csr(batch.contiguous(), nodes, size, batch.numel())
         _POOL_CACHE.clear()  # one entry: mini-batch loops bring a new batch vector every step
         _POOL_CACHE[key] = (batch, csr)
     else:
