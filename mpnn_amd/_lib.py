@@ -15,7 +15,7 @@ MPNN_F32 = 0
 MPNN_BF16 = 1
 ABI_VERSION = 2
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
+LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
 # name -> (restype, argtypes); mirrors include/mpnn_amd.h one to one.
 SIGNATURES = {

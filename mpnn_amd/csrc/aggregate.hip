@@ -41,7 +41,8 @@ struct FwdArgs {
   int H; int lpr_log2;
 };
 
-template <typename T, int VEC, int FE, bool RTFE, bool TRAIN, int U>
+// TRAIN: 0 = output only, 1 = + positive-message counts, 2 = + relu mask bits per edge.
+template <typename T, int VEC, int FE, bool RTFE, int TRAIN, int U>
 __global__ void __launch_bounds__(kBlock, MPNN_FWD_WAVES) k_agg_fwd(FwdArgs<T> a) {
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << a.lpr_log2;
@@ -71,27 +72,47 @@ __global__ void __launch_bounds__(kBlock, MPNN_FWD_WAVES) k_agg_fwd(FwdArgs<T> a
     for (int v = 0; v < VEC; ++v) { ar[v] = 0.f; acc[v] = 0.f; cn[v] = 0; }
     if (valid) RowIO<T, VEC>::load(a.A + (int64_t)row * a.ldA + cc, ar);
 
-    int nxt = (e0 + lig < e1) ? a.col[e0 + lig] : 0;
+    // Lane `lig` of the group fetches the source index and the attributes of edge base + lig (two coalesced
+    // streams, one chunk ahead); the inner loop hands them round with ds_bpermute, so its only memory
+    // instructions are the U row gathers and nothing delays their issue.
+    int nxt = 0;
+    float enx[FE];
+#pragma unroll
+    for (int f = 0; f < FE; ++f) enx[f] = 0.f;
+    if (e0 + lig < e1) {
+      nxt = a.col[e0 + lig];
+      load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(e0 + lig), a.fe, enx);
+    }
     for (int base = e0; base < e1; base += lpr) {
       const int cur = nxt;
+      float ecur[FE];
+#pragma unroll
+      for (int f = 0; f < FE; ++f) ecur[f] = enx[f];
       const int nb = (e1 - base) < lpr ? (e1 - base) : lpr;
       const int pn = base + lpr + lig;
-      nxt = pn < e1 ? a.col[pn] : 0;
+      if (pn < e1) {
+        nxt = a.col[pn];
+        load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)pn, a.fe, enx);
+      }
+      uint32_t mb[VEC < 4 ? 4 : VEC];  // relu mask words of edge base + lig, collected over the chunk
+#pragma unroll
+      for (int v = 0; v < (VEC < 4 ? 4 : VEC); ++v) mb[v] = 0u;
       for (int j = 0; j < nb; j += U) {
-        float bv[U][VEC], ev[U][FE];
-        uint32_t bits[U][VEC < 4 ? 4 : VEC];
+        float bv[U][VEC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int jj = (j + u) < nb ? (j + u) : (nb - 1);
           const int s = __shfl(cur, jj, lpr);
           RowIO<T, VEC>::load(a.B + (int64_t)s * a.ldB + cc, bv[u]);
-          load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(base + jj), a.fe, ev[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool live = (j + u) < nb;
-          float ce[VEC];
-          edge_term<VEC, FE>(w, ev[u], ce);
+          const int jj = live ? (j + u) : (nb - 1);
+          float ev[FE], ce[VEC];
+#pragma unroll
+          for (int f = 0; f < FE; ++f) ev[f] = __shfl(ecur[f], jj, lpr);
+          edge_term<VEC, FE>(w, ev, ce);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             float m = relu_f((ar[v] + bv[u][v]) + ce[v]);
@@ -100,42 +121,24 @@ __global__ void __launch_bounds__(kBlock, MPNN_FWD_WAVES) k_agg_fwd(FwdArgs<T> a
             if (TRAIN) {
               const bool pos = m > 0.f;
               cn[v] += pos ? 1 : 0;
-              if (a.maskbits) {
-                // the wave's vote as two 32-bit halves; the group's bits start at bit `gsh` of half `ghalf`
+              if (TRAIN == 2) {
+                // The wave's vote as two 32-bit halves; the group's bits start at bit `gsh` of half `ghalf`
+                // (higher bits belong to other groups; the reader tests bit `lig` only).  Lane j + u of the
+                // group keeps the words of this edge.
                 const unsigned long long vote = __ballot(pos);
-                bits[u][v] = (ghalf ? (uint32_t)(vote >> 32) : (uint32_t)vote) >> gsh;
+                const uint32_t word = (ghalf ? (uint32_t)(vote >> 32) : (uint32_t)vote) >> gsh;
+                mb[v] = (lig == j + u) ? word : mb[v];
               }
             }
           }
         }
-        if (TRAIN && VEC % 4 == 0 && a.maskbits) {
-          // The group's bits sit at the bottom of each word (higher bits belong to other groups; the reader
-          // tests bit `lig` only).  Lane u of the group stores the words of edge j + u, so the U edges of
-          // this step leave as one contiguous U * VEC * 4 byte store per group.
-          if (lpr >= U) {
-            if (lig < U && (j + lig) < nb) {
-              uint32_t w[VEC];
+      }
+      if (TRAIN == 2 && VEC % 4 == 0) {
+        // one coalesced store per chunk: lane lig writes the VEC words of edge base + lig
+        if (lig < nb) {
+          uint32_t* mp = a.maskbits + (int64_t)(base + lig) * VEC;
 #pragma unroll
-              for (int v = 0; v < VEC; ++v) w[v] = bits[0][v];
-#pragma unroll
-              for (int u = 1; u < U; ++u)
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) w[v] = (lig == u) ? bits[u][v] : w[v];
-              uint32_t* mp = a.maskbits + (int64_t)(base + j + lig) * VEC;
-#pragma unroll
-              for (int v = 0; v < VEC; v += 4) *reinterpret_cast<uint4*>(mp + v) = make_uint4(w[v], w[v + 1], w[v + 2], w[v + 3]);
-            }
-          } else if (lig == 0) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-              if ((j + u) < nb) {
-                uint32_t* mp = a.maskbits + (int64_t)(base + j + u) * VEC;
-#pragma unroll
-                for (int v = 0; v < VEC; v += 4)
-                  *reinterpret_cast<uint4*>(mp + v) = make_uint4(bits[u][v], bits[u][v + 1], bits[u][v + 2], bits[u][v + 3]);
-              }
-            }
-          }
+          for (int v = 0; v < VEC; v += 4) *reinterpret_cast<uint4*>(mp + v) = make_uint4(mb[v], mb[v + 1], mb[v + 2], mb[v + 3]);
         }
       }
     }
@@ -445,7 +448,7 @@ static int fwd_unroll() {
   return u;
 }
 
-template <typename T, int VEC, bool TRAIN, int U>
+template <typename T, int VEC, int TRAIN, int U>
 static int32_t launch_fwd_u(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
   if (a.fe == 4) k_agg_fwd<T, VEC, 4, false, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
   else if (a.fe == 1) k_agg_fwd<T, VEC, 1, false, TRAIN, U><<<grid, kBlock, 0, stream>>>(a);
@@ -454,7 +457,7 @@ static int32_t launch_fwd_u(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) 
   return MPNN_OK;
 }
 
-template <typename T, int VEC, bool TRAIN>
+template <typename T, int VEC, int TRAIN>
 static int32_t launch_fwd(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
   const int u = fwd_unroll();
   if (u == 2) return launch_fwd_u<T, VEC, TRAIN, 2>(a, grid, stream);
@@ -478,8 +481,16 @@ static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, c
   a.cnt = cnt; a.part_out = part_out; a.part_cnt = part_cnt;
   a.maskbits = maskbits;
   a.H = H; a.lpr_log2 = g.lpr_log2;
-  dim3 grid(row_grid(n_items, g.lpr_log2), g.tiles);
-  int32_t rc = cnt ? launch_fwd<T, VEC, true>(a, grid, stream) : launch_fwd<T, VEC, false>(a, grid, stream);
+  // One item per lane group while the grid allows it: the items arrive largest first, so the hardware's
+  // in-order block dispatch balances the CUs by itself; the forward kernel keeps no per-block state that
+  // would bound the grid.
+  static const int64_t max_blocks = [] { const char* e = getenv("MPNN_FWD_BLOCKS"); return e ? atoll(e) : (int64_t)1 << 16; }();
+  dim3 grid(row_grid(n_items, g.lpr_log2, max_blocks), g.tiles);
+  int32_t rc;
+  if (!cnt) rc = launch_fwd<T, VEC, 0>(a, grid, stream);
+  else if (!maskbits) rc = launch_fwd<T, VEC, 1>(a, grid, stream);
+  else if constexpr (VEC % 4 == 0) rc = launch_fwd<T, VEC, 2>(a, grid, stream);
+  else return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: mask bits need the 16-byte vector path");
   if (rc != MPNN_OK) return rc;
   if (n_split > 0) {
     rc = launch_reduce_split<T, VEC>(part_out, split, n_split, static_cast<T*>(out), ldo, H, g, stream);

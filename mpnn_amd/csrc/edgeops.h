@@ -174,11 +174,11 @@ inline Geometry geometry(int H, int dtype, bool vec_ok) {
   return g;
 }
 
-inline int row_grid(int64_t n_items, int lpr_log2) {
+inline int row_grid(int64_t n_items, int lpr_log2, int64_t max_blocks = kMaxBlocks) {
   const int per_block = (kBlock / 64) * (64 >> lpr_log2);
   int64_t g = (n_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
-  if (g > kMaxBlocks) g = kMaxBlocks;
+  if (g > max_blocks) g = max_blocks;
   return (int)g;
 }
 
