@@ -82,7 +82,11 @@ __device__ __forceinline__ float4 relu_mask4(float4 v, float4 m) {
 // [32 wr, 32 wr + 32) of the 128-row step and columns [32 MT wc, 32 MT (wc + 1)) of the block's column slice.
 // k-chunks are software-pipelined: while chunk c is multiplied out of one LDS buffer, chunk c + 1 is in
 // flight from global memory into registers and is written to the other buffer before the (single) barrier.
-template <int MT, int WC, bool ALIGNED>
+// TRANS swaps the MFMA operand roles so that the accumulator holds the transpose of the output tile: a lane then
+// owns 4 consecutive output columns of one row per register quad and the epilogue moves 16 bytes per access.
+// That pays when the epilogue also reads emul and writes Y2 (three arrays); for a single output the
+// 4-byte, whole-line pattern of the plain layout is faster.
+template <int MT, int WC, bool ALIGNED, bool TRANS>
 __global__ void __launch_bounds__(kBlock * WC) k_gemm_nt(NtArgs a) {
   constexpr int NTHREADS = kBlock * WC;
   constexpr int WROWS = 32 * MT * WC;
@@ -176,13 +180,48 @@ __global__ void __launch_bounds__(kBlock * WC) k_gemm_nt(NtArgs a) {
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
         const float4 bv = *reinterpret_cast<const float4*>(Ws + ((wc * MT + t) * 32 + li) * kLd + kq * 8 + lh * 4);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+        if (TRANS) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, acc[t], 0, 0, 0);
+        } else {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+        }
       }
     }
-    if (last_chunk) {
+    if (last_chunk && TRANS) {
+      // Transposed tile: output row = lane & 31, column within the 32-wide tile = (reg & 3) + 8 * (reg >> 2)
+      // + 4 * (lane >> 5); registers 4i..4i+3 are 4 consecutive columns.  The host picks this variant only
+      // when every output row starts on a 16-byte boundary and M % 4 == 0.
+      const int64_t row = row0 + wr * 32 + li;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = m0 + (wc * MT + t) * 32 + 8 * i + 4 * lh;
+          float4 v = make_float4(acc[t][4 * i], acc[t][4 * i + 1], acc[t][4 * i + 2], acc[t][4 * i + 3]);
+          if (a.relu) {
+            v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
+            v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
+          }
+          if (row < a.N && col < a.M) {
+            *reinterpret_cast<float4*>(a.Y + row * a.ldy + col) = v;
+            if (a.Y2) {
+              const float4 e = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
+              *reinterpret_cast<float4*>(a.Y2 + row * a.ldy2 + col) = make_float4(v.x * e.x, v.y * e.y, v.z * e.z, v.w * e.w);
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      }
+      ++step;
+      c = 0;
+    } else if (last_chunk) {
       // C layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
@@ -355,8 +394,16 @@ static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
   constexpr int WROWS = 32 * MT * WC;
   dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
   const size_t lds = (size_t)2 * (kBN + WROWS) * kLd * sizeof(float);
-  if (aligned) k_gemm_nt<MT, WC, true><<<grid, kBlock * WC, lds, stream>>>(a);
-  else k_gemm_nt<MT, WC, false><<<grid, kBlock * WC, lds, stream>>>(a);
+  // transposed accumulator tile only for the three-array epilogue, and only when 16-byte accesses are legal
+  const bool trans = a.Y2 && (a.M & 3) == 0 && ((a.ldy | a.ldy2 | a.ldemul) & 3) == 0 &&
+                     (((uintptr_t)a.Y | (uintptr_t)a.Y2 | (uintptr_t)a.emul) & 15) == 0;
+  if (trans) {
+    if (aligned) k_gemm_nt<MT, WC, true, true><<<grid, kBlock * WC, lds, stream>>>(a);
+    else k_gemm_nt<MT, WC, false, true><<<grid, kBlock * WC, lds, stream>>>(a);
+  } else {
+    if (aligned) k_gemm_nt<MT, WC, true, false><<<grid, kBlock * WC, lds, stream>>>(a);
+    else k_gemm_nt<MT, WC, false, false><<<grid, kBlock * WC, lds, stream>>>(a);
+  }
 }
 
 }  // namespace mpnn
