@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 2
+#define MPNN_ABI_VERSION 3
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -97,6 +97,75 @@ int32_t mpnn_items_build(const int32_t* rowptr, int64_t num_nodes, int32_t chunk
  * Used to lay edge_attr out in CSR order once per graph (eid / eid_t from above). */
 int32_t mpnn_gather_rows(const void* src, const int32_t* index, void* dst, int64_t rows,
                          int64_t row_bytes, mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Mini-batch assembly on the device.
+ *
+ * Replaces torch_geometric's DataLoader collation, which the reference runs in 8 CPU worker
+ * processes (data/dataset.py:94-96, 215-216; loops training/train.py:96-98), AND the per-batch
+ * rebuild of the index structure: a dataset of small graphs is block-diagonal, so it is sorted
+ * once as a whole (mpnn_csr_build over the concatenated dataset) and the CSR of a batch is the
+ * concatenation of its graphs' CSR segments with offsets.  One call writes, for the graphs placed
+ * in the batch slots:
+ *     x, pos            node rows stacked in slot order
+ *     batch[p]          slot of node p (int64, the `batch` vector of PyG)
+ *     edge_index[2][E]  dataset edge list of each graph + the slot's node offset (int64)
+ *     ea, ea_dst, ea_src  edge attributes in edge order / destination-sorted / source-sorted order
+ *     rowptr, col, eid, items of both sorted views, and tpos (transpose position -> sorted position)
+ * Work items are one per row in row order ({row, e0, e1, -1}); the caller must use the general builder
+ * for a dataset that holds a row longer than its chunk length.
+ *
+ * slots (device, int32 [5][num_slots + 1]): row 0 = first batch node of slot b, row 1 = first batch
+ * edge, row 2 = row 0 minus the first DATASET node of the slot's graph, row 3 = row 1 minus its first
+ * dataset edge, row 4 = the graph's index in the dataset (selects its row of y_all); entry num_slots
+ * of rows 0 and 1 holds the batch totals.
+ * *_all arrays are dataset-level: src_all/dst_all/col_*_all hold dataset-global node ids, eid_*_all and
+ * tpos_all dataset-global edge positions.  Row sizes are in bytes (multiples of 2).
+ * The descriptor itself is read on the host.
+ * ------------------------------------------------------------------------- */
+typedef struct mpnn_collate_desc {
+  const int32_t* slots;
+  int32_t num_slots;
+  int64_t num_nodes, num_edges; /* batch totals */
+  const void* x_all;
+  int32_t x_row_bytes;
+  const void* pos_all; /* optional */
+  int32_t pos_row_bytes;
+  const void* y_all; /* optional, one row per dataset graph */
+  int32_t y_row_bytes;
+  const int64_t* src_all;
+  const int64_t* dst_all;
+  const void* ea_all;
+  const void* ea_dst_all;
+  const void* ea_src_all;
+  int32_t ea_row_bytes;
+  const int32_t* rowptr_dst_all;
+  const int32_t* col_dst_all;
+  const int32_t* eid_dst_all;
+  const int32_t* rowptr_src_all;
+  const int32_t* col_src_all;
+  const int32_t* eid_src_all;
+  const int32_t* tpos_all;
+  /* outputs */
+  void* x;
+  void* pos;
+  void* y; /* [num_slots] rows */
+  int64_t* batch;
+  int64_t* edge_index;
+  void* ea;
+  void* ea_dst;
+  void* ea_src;
+  int32_t* rowptr_dst;
+  int32_t* col_dst;
+  int32_t* eid_dst;
+  int32_t* items_dst;
+  int32_t* rowptr_src;
+  int32_t* col_src;
+  int32_t* eid_src;
+  int32_t* items_src;
+  int32_t* tpos;
+} mpnn_collate_desc;
+int32_t mpnn_collate(const mpnn_collate_desc* desc, mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Fused message + sum aggregation, forward.

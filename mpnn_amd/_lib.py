@@ -13,12 +13,33 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
+
+
+class CollateDesc(ctypes.Structure):
+    """struct mpnn_collate_desc of include/mpnn_amd.h (field for field)."""
+    _fields_ = [
+        ("slots", c_void_p), ("num_slots", c_int32), ("num_nodes", c_int64), ("num_edges", c_int64),
+        ("x_all", c_void_p), ("x_row_bytes", c_int32), ("pos_all", c_void_p), ("pos_row_bytes", c_int32),
+        ("y_all", c_void_p), ("y_row_bytes", c_int32),
+        ("src_all", c_void_p), ("dst_all", c_void_p),
+        ("ea_all", c_void_p), ("ea_dst_all", c_void_p), ("ea_src_all", c_void_p), ("ea_row_bytes", c_int32),
+        ("rowptr_dst_all", c_void_p), ("col_dst_all", c_void_p), ("eid_dst_all", c_void_p),
+        ("rowptr_src_all", c_void_p), ("col_src_all", c_void_p), ("eid_src_all", c_void_p), ("tpos_all", c_void_p),
+        ("x", c_void_p), ("pos", c_void_p), ("y", c_void_p), ("batch", c_void_p), ("edge_index", c_void_p),
+        ("ea", c_void_p), ("ea_dst", c_void_p), ("ea_src", c_void_p),
+        ("rowptr_dst", c_void_p), ("col_dst", c_void_p), ("eid_dst", c_void_p), ("items_dst", c_void_p),
+        ("rowptr_src", c_void_p), ("col_src", c_void_p), ("eid_src", c_void_p), ("items_src", c_void_p),
+        ("tpos", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/mpnn_amd.h one to one.
 SIGNATURES = {
+    "mpnn_collate": (c_int32, [ctypes.POINTER(CollateDesc), c_void_p]),
     "mpnn_abi_version": (c_int32, []),
     "mpnn_last_error": (c_char_p, []),
     "mpnn_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),

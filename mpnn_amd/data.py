@@ -1,0 +1,202 @@
+"""Device-resident datasets of small graphs and their mini-batches.
+
+The reference batches molecules / point clouds with torch_geometric's DataLoader in 8 CPU worker
+processes (data/dataset.py:94-96, 215-216) and iterates ``for data in train_loader`` (training/train.py:96-98);
+every batch then pays for the index handling inside propagate() again.  Here the whole dataset lives on the
+GPU, its (block-diagonal) edge list is sorted once, and a mini-batch - including the sorted index structure
+the layers need - is written by one library call (mpnn_collate) with no sort and no device->host read.
+
+``Batch`` carries the attributes the reference's trainers read from a PyG batch: x, edge_index, batch,
+edge_attr, y, pos (training/train.py:21,73), and ``.to(device)``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .graph import CHUNK, CSR, MPGraph, register_graph
+from .ops import register_pool
+
+
+class Batch:
+    """The concatenation of a list of graphs (PyG ``Batch.from_data_list`` semantics)."""
+
+    def __init__(self, x, edge_index, batch, edge_attr, y, pos, num_graphs):
+        self.x, self.edge_index, self.batch, self.edge_attr, self.y, self.pos = x, edge_index, batch, edge_attr, y, pos
+        self.num_graphs = num_graphs
+        self.num_nodes = x.size(0)
+
+    def to(self, device):
+        if torch.device(device).type != self.x.device.type:
+            raise _lib.MpnnError("a device-assembled batch cannot be moved off the GPU")
+        return self
+
+
+def slot_table(node_ptr: np.ndarray, edge_ptr: np.ndarray, ids) -> np.ndarray:
+    """Host-side offsets of a batch: int32 [5, B + 1], the `slots` argument of mpnn_collate.
+
+    Row 0 / 1: first batch node / edge of every slot (entry B = totals); row 2 / 3: those minus the first dataset
+    node / edge of the slot's graph; row 4: the graph's dataset index."""
+    ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+    if ids.size == 0:
+        raise ValueError("empty batch")
+    if ids.min() < 0 or ids.max() >= len(node_ptr) - 1:
+        raise IndexError("graph index out of range")
+    b = ids.size
+    nn = node_ptr[ids + 1] - node_ptr[ids]
+    ne = edge_ptr[ids + 1] - edge_ptr[ids]
+    if nn.sum() >= 2 ** 31 or ne.sum() >= 2 ** 31:
+        raise ValueError("batch exceeds 2^31 nodes or edges")
+    t = np.zeros((5, b + 1), dtype=np.int64)
+    t[0, 1:] = np.cumsum(nn)
+    t[1, 1:] = np.cumsum(ne)
+    t[2, :b] = t[0, :b] - node_ptr[ids]
+    t[3, :b] = t[1, :b] - edge_ptr[ids]
+    t[4, :b] = ids
+    return t.astype(np.int32)
+
+
+class GraphStore:
+    """A dataset of G small graphs, concatenated on the device.
+
+    x [N_all, F], edge_index [2, E_all] with dataset-global node ids, edge_attr [E_all, Fe], node_ptr / edge_ptr
+    [G + 1] (host or device, int64): graph g owns nodes node_ptr[g]:node_ptr[g+1] and edges
+    edge_ptr[g]:edge_ptr[g+1], and its edges only join its own nodes.  y has one row per graph.
+    """
+
+    def __init__(self, x, edge_index, edge_attr, node_ptr, edge_ptr, y=None, pos=None):
+        _lib.require_device(x, "x")
+        dev = x.device
+        self.device = dev
+        self.node_ptr = np.asarray(torch.as_tensor(node_ptr).cpu().numpy(), dtype=np.int64)
+        self.edge_ptr = np.asarray(torch.as_tensor(edge_ptr).cpu().numpy(), dtype=np.int64)
+        self.num_graphs = len(self.node_ptr) - 1
+        n_all, e_all = int(self.node_ptr[-1]), int(self.edge_ptr[-1])
+        if x.size(0) != n_all or edge_index.size(1) != e_all or edge_attr.size(0) != e_all:
+            raise ValueError("node_ptr / edge_ptr totals do not match x / edge_index / edge_attr")
+        if y is not None and y.size(0) != self.num_graphs:
+            raise ValueError("y needs one row per graph")
+        self.x = x.contiguous()
+        self.pos = pos.contiguous() if pos is not None else None
+        self.y = y.contiguous() if y is not None else None
+        self.edge_attr = edge_attr.contiguous()
+        self.src = edge_index[0].contiguous()
+        self.dst = edge_index[1].contiguous()
+        # every edge must stay inside its graph's node range (block-diagonal dataset)
+        if e_all:
+            ep = torch.as_tensor(self.edge_ptr, device=dev)
+            npt = torch.as_tensor(self.node_ptr, device=dev)
+            owner = torch.searchsorted(ep, torch.arange(e_all, device=dev), right=True) - 1
+            lo, hi = npt[owner], npt[owner + 1]
+            ok = (self.src >= lo) & (self.src < hi) & (self.dst >= lo) & (self.dst < hi)
+            if not bool(ok.all()):
+                raise ValueError("an edge leaves the node range of its graph")
+        # one sort for the whole dataset
+        self.graph_all = MPGraph(torch.stack([self.src, self.dst]), n_all)
+        self.tpos_all = self.graph_all.tpos
+        self.ea_dst_all, self.ea_src_all = self.graph_all.sorted_edge_attr(self.edge_attr, self.edge_attr.dtype)
+        g = self.graph_all
+        self.max_degree = int(max(g.by_dst.degree().max().item(), g.by_src.degree().max().item())) if e_all else 0
+        # the fused path writes one work item per row, which is the general builder's result only while no row
+        # is long enough to be split
+        self.fused = self.max_degree <= CHUNK
+        self._iota = torch.arange(0, dtype=torch.int32, device=dev)
+
+    @classmethod
+    def from_batched(cls, d: dict) -> "GraphStore":
+        """Builds a store from one big batched sample (dict with x, edge_index, edge_attr, batch, y, pos):
+        edges are regrouped by the graph of their target, keeping their relative order."""
+        batch = d["batch"]
+        num_graphs = int(batch.max().item()) + 1
+        sizes = torch.bincount(batch, minlength=num_graphs)
+        node_ptr = torch.zeros(num_graphs + 1, dtype=torch.int64, device=batch.device)
+        node_ptr[1:] = torch.cumsum(sizes, 0)
+        ei = d["edge_index"]
+        eg = batch[ei[1]]
+        order = torch.sort(eg, stable=True).indices
+        esz = torch.bincount(eg, minlength=num_graphs)
+        edge_ptr = torch.zeros(num_graphs + 1, dtype=torch.int64, device=batch.device)
+        edge_ptr[1:] = torch.cumsum(esz, 0)
+        return cls(d["x"], ei[:, order], d["edge_attr"][order], node_ptr, edge_ptr, d.get("y"), d.get("pos"))
+
+    # ------------------------------------------------------------------------------------------
+    def slot_table(self, ids) -> np.ndarray:
+        return slot_table(self.node_ptr, self.edge_ptr, ids)
+
+    def collate(self, ids) -> Batch:
+        """Mini-batch of the graphs ``ids`` (host sequence), in that order."""
+        table = self.slot_table(ids)
+        b = table.shape[1] - 1
+        n, e = int(table[0, b]), int(table[1, b])
+        dev = self.device
+        slots = torch.from_numpy(table).to(dev, non_blocking=True)
+        i32 = dict(dtype=torch.int32, device=dev)
+        x = torch.empty((n,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=dev)
+        pos = torch.empty((n,) + tuple(self.pos.shape[1:]), dtype=self.pos.dtype, device=dev) if self.pos is not None else None
+        y = torch.empty((b,) + tuple(self.y.shape[1:]), dtype=self.y.dtype, device=dev) if self.y is not None else None
+        batch = torch.empty(n, dtype=torch.int64, device=dev)
+        edge_index = torch.empty((2, e), dtype=torch.int64, device=dev)
+        ea = torch.empty((e,) + tuple(self.edge_attr.shape[1:]), dtype=self.edge_attr.dtype, device=dev)
+        ea_dst, ea_src = torch.empty_like(ea), torch.empty_like(ea)
+        ints = torch.empty(2 * (n + 1) + 5 * e, **i32)        # rowptr x2, col/eid x2, tpos
+        items = torch.empty((2, max(n, 1), 4), **i32)
+        rowptr_dst, rowptr_src = ints[:n + 1], ints[n + 1:2 * (n + 1)]
+        o = 2 * (n + 1)
+        col_dst, eid_dst, col_src, eid_src, tpos = (ints[o + k * e:o + (k + 1) * e] for k in range(5))
+        ga = self.graph_all
+        row_bytes = lambda t: int(np.prod(t.shape[1:], dtype=np.int64)) * t.element_size()
+        d = _lib.CollateDesc(
+            slots=_lib.ptr(slots), num_slots=b, num_nodes=n, num_edges=e,
+            x_all=_lib.ptr(self.x), x_row_bytes=row_bytes(self.x),
+            pos_all=_lib.ptr(self.pos), pos_row_bytes=row_bytes(self.pos) if self.pos is not None else 0,
+            y_all=_lib.ptr(self.y), y_row_bytes=row_bytes(self.y) if self.y is not None else 0,
+            src_all=_lib.ptr(self.src), dst_all=_lib.ptr(self.dst),
+            ea_all=_lib.ptr(self.edge_attr), ea_dst_all=_lib.ptr(self.ea_dst_all), ea_src_all=_lib.ptr(self.ea_src_all),
+            ea_row_bytes=row_bytes(self.edge_attr),
+            rowptr_dst_all=_lib.ptr(ga.by_dst.rowptr), col_dst_all=_lib.ptr(ga.by_dst.col), eid_dst_all=_lib.ptr(ga.by_dst.eid),
+            rowptr_src_all=_lib.ptr(ga.by_src.rowptr), col_src_all=_lib.ptr(ga.by_src.col), eid_src_all=_lib.ptr(ga.by_src.eid),
+            tpos_all=_lib.ptr(self.tpos_all),
+            x=_lib.ptr(x), pos=_lib.ptr(pos), y=_lib.ptr(y), batch=_lib.ptr(batch), edge_index=_lib.ptr(edge_index),
+            ea=_lib.ptr(ea), ea_dst=_lib.ptr(ea_dst), ea_src=_lib.ptr(ea_src),
+            rowptr_dst=_lib.ptr(rowptr_dst), col_dst=_lib.ptr(col_dst), eid_dst=_lib.ptr(eid_dst), items_dst=_lib.ptr(items[0]),
+            rowptr_src=_lib.ptr(rowptr_src), col_src=_lib.ptr(col_src), eid_src=_lib.ptr(eid_src), items_src=_lib.ptr(items[1]),
+            tpos=_lib.ptr(tpos))
+        lib = _lib.load()
+        _lib.check(lib.mpnn_collate(ctypes.byref(d), _lib.stream_handle(dev)), "mpnn_collate")
+        out = Batch(x, edge_index, batch, ea, y, pos, b)
+        if self.fused:
+            views = []
+            for rowptr, col, eid, it in ((rowptr_dst, col_dst, eid_dst, items[0]), (rowptr_src, col_src, eid_src, items[1])):
+                c = CSR()
+                c.num_rows, c.num_cols, c.num_edges = n, n, e
+                c.rowptr, c.col, c.eid, c.items, c.split = rowptr, col, eid, it, None
+                c.n_items, c.n_parts, c.n_split = n, 0, 0
+                views.append(c)
+            g = MPGraph.from_parts(views[0], views[1], tpos)
+            g.seed_edge_attr(ea, ea_dst, ea_src)
+            register_graph(edge_index, n, g)
+        if self._iota.numel() < n:
+            self._iota = torch.arange(max(n, 2 * self._iota.numel()), **i32)
+        register_pool(batch, b, slots[0], self._iota[:n])
+        return out
+
+
+class GraphLoader:
+    """``for data in loader`` over mini-batches of a GraphStore (DataLoader(batch_size, shuffle) of the reference,
+    data/dataset.py:94-96): the last batch may be short; a shuffling loader draws a new order every epoch."""
+
+    def __init__(self, store: GraphStore, batch_size: int = 32, shuffle: bool = False, seed: int = 0, indices=None):
+        self.store, self.batch_size, self.shuffle = store, int(batch_size), shuffle
+        self.indices = np.arange(store.num_graphs) if indices is None else np.asarray(indices, dtype=np.int64)
+        self._rng = np.random.default_rng(seed)
+
+    def __len__(self):
+        return (len(self.indices) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        order = self._rng.permutation(self.indices) if self.shuffle else self.indices
+        for i in range(0, len(order), self.batch_size):
+            yield self.store.collate(order[i:i + self.batch_size])

@@ -110,6 +110,25 @@ class MPGraph:
         self._scratch = {}
         self._tpos = None
 
+    @classmethod
+    def from_parts(cls, by_dst: CSR, by_src: CSR, tpos: torch.Tensor | None = None) -> "MPGraph":
+        """Wraps index structures that were produced elsewhere (the batch assembler writes them directly)."""
+        g = cls.__new__(cls)
+        g.num_dst, g.num_src, g.num_edges = by_dst.num_rows, by_src.num_rows, by_dst.num_edges
+        g.by_dst, g.by_src = by_dst, by_src
+        g._ea_key = None
+        g._ea_sorted = None
+        g._scratch = {}
+        g._tpos = tpos
+        return g
+
+    def seed_edge_attr(self, edge_attr: torch.Tensor, ea_dst: torch.Tensor, ea_src: torch.Tensor) -> None:
+        """Registers the two sorted layouts of ``edge_attr`` when the caller already holds them."""
+        self._ea_key = (edge_attr.data_ptr(), edge_attr._version, tuple(edge_attr.shape), edge_attr.dtype,
+                        edge_attr.dtype)
+        self._ea_holder = edge_attr
+        self._ea_sorted = (ea_dst, ea_src)
+
     @property
     def tpos(self) -> torch.Tensor:
         """tpos[p] = position in the destination-sorted CSR of the edge at transpose position p."""
@@ -174,6 +193,16 @@ def graph_for(edge_index: torch.Tensor, num_nodes: int) -> MPGraph:
     while len(_CACHE) > _CACHE_SIZE:
         _CACHE.popitem(last=False)
     return g
+
+
+def register_graph(edge_index: torch.Tensor, num_nodes: int, g: MPGraph) -> None:
+    """Puts a ready-made MPGraph into the cache under the key graph_for() will compute for ``edge_index``."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
+           str(edge_index.device), int(num_nodes))
+    _CACHE[key] = (edge_index, g)
+    _CACHE.move_to_end(key)
+    while len(_CACHE) > _CACHE_SIZE:
+        _CACHE.popitem(last=False)
 
 
 def clear_cache() -> None:

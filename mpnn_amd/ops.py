@@ -319,6 +319,17 @@ class _SegmentMean(torch.autograd.Function):
 _POOL_CACHE = {}
 
 
+def register_pool(batch: torch.Tensor, num_graphs: int, rowptr: torch.Tensor, col: torch.Tensor) -> None:
+    """Seeds the segment structure of ``batch`` (sorted, graph b owns nodes rowptr[b]:rowptr[b+1]; ``col`` is
+    the node list in segment order) so that global_mean_pool need not derive it - the batch assembler
+    already knows it."""
+    csr = CSR()
+    csr.num_rows, csr.num_cols, csr.num_edges = int(num_graphs), batch.numel(), batch.numel()
+    csr.rowptr, csr.col = rowptr, col
+    _POOL_CACHE.clear()
+    _POOL_CACHE[(batch.data_ptr(), batch._version, batch.numel(), str(batch.device), None)] = (batch, csr)
+
+
 @torch.compiler.disable
 def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: int | None = None) -> torch.Tensor:
     """Per-graph mean of node rows; same contract as PyG's global_mean_pool (models/mpnn.py:54,150)."""

@@ -244,3 +244,33 @@ def egnn_layer(a, b, edge_attr, w_edge, pos, w_pos, edge_index):
     s = (m * w_pos.view(1, -1)).sum(dim=1, keepdim=True)
     rel = gather_dst(pos, edge_index) - gather_src(pos, edge_index)
     return aggr, pos + scatter_sum(rel * s, edge_index, pos.size(0))
+
+
+# ----------------------------------------------------------------------------
+# mini-batch collation (torch_geometric DataLoader semantics)
+# ----------------------------------------------------------------------------
+def collate(x, edge_index, edge_attr, node_ptr, edge_ptr, ids, y=None, pos=None) -> dict:
+    """Batch of the graphs ``ids`` of a concatenated dataset, as torch_geometric's ``Batch.from_data_list`` builds
+    it for the reference's loaders (data/dataset.py:94-96, 215-216): node rows, targets and edges of the listed
+    graphs concatenated in list order, every graph's LOCAL edge_index shifted by the number of nodes before it,
+    and ``batch[p]`` = position in the list of the graph node p came from.  ``edge_index`` here holds
+    dataset-global node ids, so a graph's local ids are its ids minus node_ptr[g].  Plain Python loop."""
+    xs, eis, eas, bs, ys, ps = [], [], [], [], [], []
+    n_before = 0
+    for slot, g in enumerate(int(i) for i in ids):
+        n0, n1 = int(node_ptr[g]), int(node_ptr[g + 1])
+        e0, e1 = int(edge_ptr[g]), int(edge_ptr[g + 1])
+        xs.append(x[n0:n1])
+        if pos is not None:
+            ps.append(pos[n0:n1])
+        if y is not None:
+            ys.append(y[g:g + 1])
+        eis.append(edge_index[:, e0:e1] - n0 + n_before)
+        eas.append(edge_attr[e0:e1])
+        bs.append(torch.full((n1 - n0,), slot, dtype=torch.int64))
+        n_before += n1 - n0
+    return {
+        "x": torch.cat(xs), "edge_index": torch.cat(eis, dim=1), "edge_attr": torch.cat(eas), "batch": torch.cat(bs),
+        "y": torch.cat(ys) if y is not None else None, "pos": torch.cat(ps) if pos is not None else None,
+        "num_nodes": n_before,
+    }
