@@ -337,6 +337,30 @@ int32_t mpnn_segment_mean_bwd(const void* gout, int64_t ldg, const int32_t* rowp
                               int64_t num_segments, int32_t H, int32_t dtype,
                               mpnn_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Loss and optimizer step (each a fixed sequence of launches, nothing read back to the host,
+ * so a whole training step can be captured into a HIP graph).
+ *
+ * mpnn_masked_ce: mean cross-entropy over the rows with mask != 0 (mask == NULL: every row), what the
+ * reference computes as F.cross_entropy(out[data.train_mask], data.y[data.train_mask])
+ * (training/train.py:47 with experiments/flickr_exp.py:31).
+ *   logits [n, c] float, labels [n] int64, mask [n] bytes (torch.bool storage)
+ *   grad   [n, c]  softmax - onehot on masked rows, 0 elsewhere - NOT yet divided by the row count
+ *   result [2]     { loss, 1 / number of masked rows }   (the gradient of the loss is grad * result[1])
+ *   scratch        mpnn_masked_ce_scratch_floats() floats
+ *
+ * mpnn_adam_step: one step of torch.optim.Adam(lr, betas, eps) without weight decay or amsgrad
+ * (experiments/flickr_exp.py:26, qm9_exp.py:33, modelnet_exp.py:49) over one flat float buffer.
+ *   state [3] (device): state[0] holds the number of steps taken so far (0 before the first call) and is
+ *   incremented by the call; state[1..2] are overwritten with the bias-corrected step size and sqrt(1-beta2^t).
+ * ------------------------------------------------------------------------- */
+int64_t mpnn_masked_ce_scratch_floats(void);
+int32_t mpnn_masked_ce(const float* logits, int64_t ld, const int64_t* labels, const uint8_t* mask, int64_t n,
+                       int32_t c, float* grad, int64_t ldg, float* result, float* scratch,
+                       mpnn_stream_t stream);
+int32_t mpnn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float* state, float lr, float beta1, float beta2, float eps, mpnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

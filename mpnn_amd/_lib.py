@@ -40,6 +40,11 @@ class CollateDesc(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/mpnn_amd.h one to one.
 SIGNATURES = {
     "mpnn_collate": (c_int32, [ctypes.POINTER(CollateDesc), c_void_p]),
+    "mpnn_masked_ce_scratch_floats": (c_int64, []),
+    "mpnn_masked_ce": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64,
+                                 c_void_p, c_void_p, c_void_p]),
+    "mpnn_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, ctypes.c_float,
+                                 ctypes.c_float, ctypes.c_float, ctypes.c_float, c_void_p]),
     "mpnn_abi_version": (c_int32, []),
     "mpnn_last_error": (c_char_p, []),
     "mpnn_csr_workspace_bytes": (c_int64, [c_int64, c_int64]),

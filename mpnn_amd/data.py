@@ -28,6 +28,7 @@ class Batch:
         self.x, self.edge_index, self.batch, self.edge_attr, self.y, self.pos = x, edge_index, batch, edge_attr, y, pos
         self.num_graphs = num_graphs
         self.num_nodes = x.size(0)
+        self._parts = None
 
     def to(self, device):
         if torch.device(device).type != self.x.device.type:
@@ -126,62 +127,79 @@ class GraphStore:
     def slot_table(self, ids) -> np.ndarray:
         return slot_table(self.node_ptr, self.edge_ptr, ids)
 
-    def collate(self, ids) -> Batch:
-        """Mini-batch of the graphs ``ids`` (host sequence), in that order."""
+    def collate(self, ids, out: Batch | None = None) -> Batch:
+        """Mini-batch of the graphs ``ids`` (host sequence), in that order.
+
+        ``out``: a batch returned earlier with the same number of graphs, nodes and edges; its tensors are
+        overwritten in place (fixed-size point-cloud batches), so code captured into a HIP graph that reads them
+        sees the new batch on its next replay."""
         table = self.slot_table(ids)
         b = table.shape[1] - 1
         n, e = int(table[0, b]), int(table[1, b])
         dev = self.device
-        slots = torch.from_numpy(table).to(dev, non_blocking=True)
+        if out is not None:
+            if (out.num_graphs, out.num_nodes, out.edge_index.size(1)) != (b, n, e) or out._parts is None:
+                raise ValueError("collate(out=...) needs a batch of identical size produced by this store")
+            out._parts["slots"].copy_(torch.from_numpy(table), non_blocking=True)
+            self._launch(out._parts, b, n, e)
+            return out
         i32 = dict(dtype=torch.int32, device=dev)
-        x = torch.empty((n,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=dev)
-        pos = torch.empty((n,) + tuple(self.pos.shape[1:]), dtype=self.pos.dtype, device=dev) if self.pos is not None else None
-        y = torch.empty((b,) + tuple(self.y.shape[1:]), dtype=self.y.dtype, device=dev) if self.y is not None else None
-        batch = torch.empty(n, dtype=torch.int64, device=dev)
-        edge_index = torch.empty((2, e), dtype=torch.int64, device=dev)
-        ea = torch.empty((e,) + tuple(self.edge_attr.shape[1:]), dtype=self.edge_attr.dtype, device=dev)
-        ea_dst, ea_src = torch.empty_like(ea), torch.empty_like(ea)
         ints = torch.empty(2 * (n + 1) + 5 * e, **i32)        # rowptr x2, col/eid x2, tpos
         items = torch.empty((2, max(n, 1), 4), **i32)
-        rowptr_dst, rowptr_src = ints[:n + 1], ints[n + 1:2 * (n + 1)]
         o = 2 * (n + 1)
-        col_dst, eid_dst, col_src, eid_src, tpos = (ints[o + k * e:o + (k + 1) * e] for k in range(5))
-        ga = self.graph_all
-        row_bytes = lambda t: int(np.prod(t.shape[1:], dtype=np.int64)) * t.element_size()
-        d = _lib.CollateDesc(
-            slots=_lib.ptr(slots), num_slots=b, num_nodes=n, num_edges=e,
-            x_all=_lib.ptr(self.x), x_row_bytes=row_bytes(self.x),
-            pos_all=_lib.ptr(self.pos), pos_row_bytes=row_bytes(self.pos) if self.pos is not None else 0,
-            y_all=_lib.ptr(self.y), y_row_bytes=row_bytes(self.y) if self.y is not None else 0,
-            src_all=_lib.ptr(self.src), dst_all=_lib.ptr(self.dst),
-            ea_all=_lib.ptr(self.edge_attr), ea_dst_all=_lib.ptr(self.ea_dst_all), ea_src_all=_lib.ptr(self.ea_src_all),
-            ea_row_bytes=row_bytes(self.edge_attr),
-            rowptr_dst_all=_lib.ptr(ga.by_dst.rowptr), col_dst_all=_lib.ptr(ga.by_dst.col), eid_dst_all=_lib.ptr(ga.by_dst.eid),
-            rowptr_src_all=_lib.ptr(ga.by_src.rowptr), col_src_all=_lib.ptr(ga.by_src.col), eid_src_all=_lib.ptr(ga.by_src.eid),
-            tpos_all=_lib.ptr(self.tpos_all),
-            x=_lib.ptr(x), pos=_lib.ptr(pos), y=_lib.ptr(y), batch=_lib.ptr(batch), edge_index=_lib.ptr(edge_index),
-            ea=_lib.ptr(ea), ea_dst=_lib.ptr(ea_dst), ea_src=_lib.ptr(ea_src),
-            rowptr_dst=_lib.ptr(rowptr_dst), col_dst=_lib.ptr(col_dst), eid_dst=_lib.ptr(eid_dst), items_dst=_lib.ptr(items[0]),
-            rowptr_src=_lib.ptr(rowptr_src), col_src=_lib.ptr(col_src), eid_src=_lib.ptr(eid_src), items_src=_lib.ptr(items[1]),
-            tpos=_lib.ptr(tpos))
-        lib = _lib.load()
-        _lib.check(lib.mpnn_collate(ctypes.byref(d), _lib.stream_handle(dev)), "mpnn_collate")
-        out = Batch(x, edge_index, batch, ea, y, pos, b)
+        ea3 = torch.empty((3, e) + tuple(self.edge_attr.shape[1:]), dtype=self.edge_attr.dtype, device=dev)
+        parts = dict(
+            slots=torch.from_numpy(table).to(dev, non_blocking=True),
+            x=torch.empty((n,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=dev),
+            pos=torch.empty((n,) + tuple(self.pos.shape[1:]), dtype=self.pos.dtype, device=dev) if self.pos is not None else None,
+            y=torch.empty((b,) + tuple(self.y.shape[1:]), dtype=self.y.dtype, device=dev) if self.y is not None else None,
+            batch=torch.empty(n, dtype=torch.int64, device=dev),
+            edge_index=torch.empty((2, e), dtype=torch.int64, device=dev),
+            ea=ea3[0], ea_dst=ea3[1], ea_src=ea3[2],
+            rowptr_dst=ints[:n + 1], rowptr_src=ints[n + 1:o], items_dst=items[0], items_src=items[1])
+        for k, name in enumerate(("col_dst", "eid_dst", "col_src", "eid_src", "tpos")):
+            parts[name] = ints[o + k * e:o + (k + 1) * e]
+        self._launch(parts, b, n, e)
+        res = Batch(parts["x"], parts["edge_index"], parts["batch"], parts["ea"], parts["y"], parts["pos"], b)
+        res._parts = parts
         if self.fused:
             views = []
-            for rowptr, col, eid, it in ((rowptr_dst, col_dst, eid_dst, items[0]), (rowptr_src, col_src, eid_src, items[1])):
+            for sfx in ("dst", "src"):
                 c = CSR()
                 c.num_rows, c.num_cols, c.num_edges = n, n, e
-                c.rowptr, c.col, c.eid, c.items, c.split = rowptr, col, eid, it, None
+                c.rowptr, c.col, c.eid = parts["rowptr_" + sfx], parts["col_" + sfx], parts["eid_" + sfx]
+                c.items, c.split = parts["items_" + sfx], None
                 c.n_items, c.n_parts, c.n_split = n, 0, 0
                 views.append(c)
-            g = MPGraph.from_parts(views[0], views[1], tpos)
-            g.seed_edge_attr(ea, ea_dst, ea_src)
-            register_graph(edge_index, n, g)
+            g = MPGraph.from_parts(views[0], views[1], parts["tpos"])
+            g.seed_edge_attr(parts["ea"], parts["ea_dst"], parts["ea_src"])
+            register_graph(parts["edge_index"], n, g)
         if self._iota.numel() < n:
             self._iota = torch.arange(max(n, 2 * self._iota.numel()), **i32)
-        register_pool(batch, b, slots[0], self._iota[:n])
-        return out
+        register_pool(parts["batch"], b, parts["slots"][0], self._iota[:n])
+        return res
+
+    def _launch(self, t: dict, b: int, n: int, e: int) -> None:
+        ga = self.graph_all
+        row_bytes = lambda a: int(np.prod(a.shape[1:], dtype=np.int64)) * a.element_size()
+        P = _lib.ptr
+        d = _lib.CollateDesc(
+            slots=P(t["slots"]), num_slots=b, num_nodes=n, num_edges=e,
+            x_all=P(self.x), x_row_bytes=row_bytes(self.x),
+            pos_all=P(self.pos), pos_row_bytes=row_bytes(self.pos) if self.pos is not None else 0,
+            y_all=P(self.y), y_row_bytes=row_bytes(self.y) if self.y is not None else 0,
+            src_all=P(self.src), dst_all=P(self.dst),
+            ea_all=P(self.edge_attr), ea_dst_all=P(self.ea_dst_all), ea_src_all=P(self.ea_src_all),
+            ea_row_bytes=row_bytes(self.edge_attr),
+            rowptr_dst_all=P(ga.by_dst.rowptr), col_dst_all=P(ga.by_dst.col), eid_dst_all=P(ga.by_dst.eid),
+            rowptr_src_all=P(ga.by_src.rowptr), col_src_all=P(ga.by_src.col), eid_src_all=P(ga.by_src.eid),
+            tpos_all=P(self.tpos_all),
+            x=P(t["x"]), pos=P(t["pos"]), y=P(t["y"]), batch=P(t["batch"]), edge_index=P(t["edge_index"]),
+            ea=P(t["ea"]), ea_dst=P(t["ea_dst"]), ea_src=P(t["ea_src"]),
+            rowptr_dst=P(t["rowptr_dst"]), col_dst=P(t["col_dst"]), eid_dst=P(t["eid_dst"]), items_dst=P(t["items_dst"]),
+            rowptr_src=P(t["rowptr_src"]), col_src=P(t["col_src"]), eid_src=P(t["eid_src"]), items_src=P(t["items_src"]),
+            tpos=P(t["tpos"]))
+        _lib.check(_lib.load().mpnn_collate(ctypes.byref(d), _lib.stream_handle(self.device)), "mpnn_collate")
 
 
 class GraphLoader:

@@ -1,0 +1,113 @@
+"""Training steps with the reference's trainer interface (training/train.py:11-82).
+
+``Trainer_QM9``, ``Trainer_Flickr`` and ``Trainer_ModelNet`` take (model, optimizer, loss_fn, device) and offer
+``train(data) -> float`` and ``test(data) -> float`` exactly like the reference's classes, including its choice
+of scoring only graph 0 of a batch (``loss_fn(out[0], data.y[0])``, training/train.py:22,74).  ``data`` is
+anything with the attributes the reference reads (x / pos, edge_index, batch, edge_attr, y, train_mask,
+test_mask): a ``mpnn_amd.data.Batch`` or a plain namespace.
+
+``CapturedStep`` records one whole training step (forward, loss, backward, optimizer) into a HIP graph when the
+step's tensors keep their addresses and shapes - a full-graph trainer, or fixed-size point-cloud batches written
+into the same buffers - and replays it with no per-launch host work.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .loss import masked_cross_entropy
+
+
+def _dev(t, device):
+    return t if t.device == torch.device(device) else t.to(device)
+
+
+class Trainer_QM9:
+    def __init__(self, model, optimizer, loss_fn, device):
+        self.model, self.optimizer, self.loss_fn, self.device = model, optimizer, loss_fn, device
+
+    def _forward(self, data):
+        d = self.device
+        return self.model(_dev(data.x, d), _dev(data.edge_index, d), _dev(data.batch, d), _dev(data.edge_attr, d))
+
+    def train(self, data):
+        self.model.train()
+        self.optimizer.zero_grad()
+        out = self._forward(data)
+        loss = self.loss_fn(out[0], _dev(data.y, self.device)[0])
+        loss.backward()
+        self.optimizer.step()
+        return loss.item()
+
+    def test(self, data):
+        self.model.eval()
+        with torch.no_grad():
+            out = self._forward(data)
+            return self.loss_fn(out[0], _dev(data.y, self.device)[0]).item()
+
+
+class Trainer_ModelNet(Trainer_QM9):
+    """Same step with the point coordinates as node features (training/train.py:73)."""
+
+    def _forward(self, data):
+        d = self.device
+        return self.model(_dev(data.pos, d), _dev(data.edge_index, d), _dev(data.batch, d), _dev(data.edge_attr, d))
+
+
+class Trainer_Flickr:
+    """Transductive full-graph trainer (training/train.py:33-58).  With ``F.cross_entropy`` as the loss the masked
+    mean is computed by the fused kernel (same value, no row compaction); any other loss takes the reference's
+    indexing path."""
+
+    def __init__(self, model, optimizer, loss_fn, device):
+        self.model, self.optimizer, self.loss_fn, self.device = model, optimizer, loss_fn, device
+
+    def loss(self, out, data):
+        y, mask = _dev(data.y, self.device), _dev(data.train_mask, self.device)
+        if self.loss_fn is F.cross_entropy and out.is_cuda and out.dtype == torch.float32:
+            return masked_cross_entropy(out, y, mask)
+        return self.loss_fn(out[mask], y[mask])
+
+    def train(self, data):
+        self.model.train()
+        self.optimizer.zero_grad()
+        d = self.device
+        out = self.model(_dev(data.x, d), _dev(data.edge_index, d), _dev(data.edge_attr, d))
+        loss = self.loss(out, data)
+        loss.backward()
+        self.optimizer.step()
+        return loss.item()
+
+    def test(self, data):
+        """Accuracy on test_mask.  (The reference's test() omits edge_attr from the model call,
+        training/train.py:54, which its own MPNN.forward does not accept; it is passed here.)"""
+        self.model.eval()
+        with torch.no_grad():
+            d = self.device
+            out = self.model(_dev(data.x, d), _dev(data.edge_index, d), _dev(data.edge_attr, d))
+            pred = out.argmax(dim=1)
+            mask, y = _dev(data.test_mask, d), _dev(data.y, d)
+            return ((pred == y) & mask).sum().item() / mask.sum().item()
+
+
+class CapturedStep:
+    """One training step as a HIP graph.
+
+    ``step_fn()`` must run the whole step on tensors that stay where they are (zero_grad that keeps the gradient
+    tensors, forward, loss, backward, optimizer step without host reads - e.g. FlatAdam) and return the loss
+    tensor.  ``replay()`` relaunches it and returns that same (device) loss tensor."""
+
+    def __init__(self, step_fn, warmup: int = 3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step_fn()
+
+    def replay(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.loss

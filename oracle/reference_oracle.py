@@ -274,3 +274,25 @@ def collate(x, edge_index, edge_attr, node_ptr, edge_ptr, ids, y=None, pos=None)
         "y": torch.cat(ys) if y is not None else None, "pos": torch.cat(ps) if pos is not None else None,
         "num_nodes": n_before,
     }
+
+
+# ----------------------------------------------------------------------------
+# loss and optimizer step of the training loop
+# ----------------------------------------------------------------------------
+def masked_cross_entropy(logits, labels, mask=None):
+    """F.cross_entropy(out[mask], y[mask]) (training/train.py:47) written as a mask-weighted mean, float64."""
+    x = logits.double()
+    lse = torch.logsumexp(x, dim=1)
+    picked = x.gather(1, labels.view(-1, 1)).squeeze(1)
+    w = torch.ones_like(lse) if mask is None else mask.double()
+    return ((lse - picked) * w).sum() / w.sum()
+
+
+def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One torch.optim.Adam step (no weight decay, no amsgrad) on plain tensors, in the dtype of ``p``;
+    ``t`` is the 1-based step number.  Returns (p, m, v)."""
+    m = m + (g - m) * (1 - beta1)
+    v = v * beta2 + (1 - beta2) * g * g
+    step_size = lr / (1 - beta1 ** t)
+    denom = v.sqrt() / (1 - beta2 ** t) ** 0.5 + eps
+    return p - step_size * (m / denom), m, v

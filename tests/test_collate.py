@@ -3,6 +3,7 @@ oracle and against the general graph builder (GPU)."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import reference_oracle as ro
 from conftest import assert_close
@@ -143,3 +144,43 @@ def test_loader_covers_every_graph_once_per_epoch():
         seen.append(data.y[:, 0].cpu())
     assert sizes == [32, 32, 6]
     assert torch.equal(torch.sort(torch.cat(seen)).values, torch.sort(store.y[:, 0].cpu()).values)
+
+
+@pytest.mark.gpu
+def test_collate_into_the_same_buffers_feeds_a_captured_step():
+    """Fixed-size clouds: a new batch is written over the old one and a captured training step, replayed,
+    computes what an eager step on a freshly allocated batch computes."""
+    from mpnn_amd import MPNN_ModelNet
+    from mpnn_amd.optim import FlatAdam
+    from mpnn_amd.train import CapturedStep
+    from mpnn_amd.graph import clear_cache
+    store, _ = _store_and_cpu("modelnet", 12)
+    models, opts = [], []
+    for _ in range(2):
+        torch.manual_seed(7)
+        m = MPNN_ModelNet(3, 1, 32, 10, num_layers=2, mode="sum").cuda()
+        models.append(m)
+        opts.append(FlatAdam(m.parameters(), lr=1e-2))
+
+    def step_on(m, o, b):
+        o.zero_grad()
+        loss = F.cross_entropy(m(b.pos, b.edge_index, b.batch, b.edge_attr), b.y)
+        loss.backward()
+        o.step()
+        return loss
+
+    batches = [[0, 1, 2, 3], [7, 5, 11, 2], [4, 4, 9, 10]]
+    fixed = store.collate(batches[0])
+    cap = CapturedStep(lambda: step_on(models[1], opts[1], fixed), warmup=2)
+    for _ in range(2):
+        step_on(models[0], opts[0], store.collate(batches[0]))
+    for ids in batches[1:] + batches[:1]:
+        le = step_on(models[0], opts[0], store.collate(ids))
+        store.collate(ids, out=fixed)
+        lc = cap.replay()
+        assert torch.equal(le, lc)
+    for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+        assert torch.equal(pa, pb)
+    with pytest.raises(ValueError):
+        store.collate([0, 1], out=fixed)
+    clear_cache()
