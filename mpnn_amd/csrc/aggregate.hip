@@ -42,8 +42,13 @@ struct FwdArgs {
 };
 
 // TRAIN: 0 = output only, 1 = + positive-message counts, 2 = + relu mask bits per edge.
+// Waves per SIMD the kernel is compiled for: the per-lane edge weights take VEC * FE registers, so the widest
+// instantiation (bfloat16 rows with the generic edge width) gets a larger register budget instead of spilling
+// hundreds of bytes.  (bfloat16 rows with Fe = 4 are faster at 4 waves with a 36-byte spill than at 3 without.)
+constexpr int fwd_waves(int vec, int fe) { return vec * fe >= 64 ? 2 : MPNN_FWD_WAVES; }
+
 template <typename T, int VEC, int FE, bool RTFE, int TRAIN, int U>
-__global__ void __launch_bounds__(kBlock, MPNN_FWD_WAVES) k_agg_fwd(FwdArgs<T> a) {
+__global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<T> a) {
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << a.lpr_log2;
   const int lig = lane & (lpr - 1);
@@ -98,24 +103,25 @@ __global__ void __launch_bounds__(kBlock, MPNN_FWD_WAVES) k_agg_fwd(FwdArgs<T> a
 #pragma unroll
       for (int v = 0; v < (VEC < 4 ? 4 : VEC); ++v) mb[v] = 0u;
       for (int j = 0; j < nb; j += U) {
-        float bv[U][VEC];
+        typename RowIO<T, VEC>::Raw braw[U];   // rows in flight stay in their storage format
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int jj = (j + u) < nb ? (j + u) : (nb - 1);
           const int s = __shfl(cur, jj, lpr);
-          RowIO<T, VEC>::load(a.B + (int64_t)s * a.ldB + cc, bv[u]);
+          braw[u] = RowIO<T, VEC>::load_raw(a.B + (int64_t)s * a.ldB + cc);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool live = (j + u) < nb;
           const int jj = live ? (j + u) : (nb - 1);
-          float ev[FE], ce[VEC];
+          float ev[FE], ce[VEC], bv[VEC];
 #pragma unroll
           for (int f = 0; f < FE; ++f) ev[f] = __shfl(ecur[f], jj, lpr);
           edge_term<VEC, FE>(w, ev, ce);
+          RowIO<T, VEC>::unpack(braw[u], bv);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            float m = relu_f((ar[v] + bv[u][v]) + ce[v]);
+            float m = relu_f((ar[v] + bv[v]) + ce[v]);
             m = live ? m : 0.f;
             acc[v] += m;
             if (TRAIN) {
@@ -438,14 +444,16 @@ __global__ void __launch_bounds__(kBlock) k_segment_mean_bwd(const T* __restrict
 // ---------------------------------------------------------------------------------------
 // Host-side dispatch
 // ---------------------------------------------------------------------------------------
-// Row gathers kept in flight per lane by the forward kernel (tuning knob; MPNN_FWD_U=2|4|8 overrides).
-static int fwd_unroll() {
-  static int u = [] {
+// Row gathers kept in flight per lane by the forward kernel: 4, or 2 when a lane owns 8 columns (bfloat16 rows),
+// where 4 would push the kernel past its register budget and into scratch.  MPNN_FWD_U=2|4 overrides (tuning).
+static int fwd_unroll(int vec) {
+  static int forced = [] {
     const char* e = getenv("MPNN_FWD_U");
-    int v = e ? atoi(e) : 4;
-    return (v == 2 || v == 8) ? v : 4;
+    const int v = e ? atoi(e) : 0;
+    return (v == 2 || v == 4) ? v : 0;
   }();
-  return u;
+  if (forced) return forced;
+  return vec >= 8 ? 2 : 4;
 }
 
 template <typename T, int VEC, int TRAIN, int U>
@@ -459,9 +467,7 @@ static int32_t launch_fwd_u(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) 
 
 template <typename T, int VEC, int TRAIN>
 static int32_t launch_fwd(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
-  const int u = fwd_unroll();
-  if (u == 2) return launch_fwd_u<T, VEC, TRAIN, 2>(a, grid, stream);
-  if (u == 8) return launch_fwd_u<T, VEC, TRAIN, 8>(a, grid, stream);
+  if (fwd_unroll(VEC) == 2) return launch_fwd_u<T, VEC, TRAIN, 2>(a, grid, stream);
   return launch_fwd_u<T, VEC, TRAIN, 4>(a, grid, stream);
 }
 

@@ -21,8 +21,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
 template <typename T, int VEC>
 struct RowIO;
 
+// `Raw` is the lane's share of a row as it sits in memory; keeping gathered rows in this form until they are
+// consumed halves the registers a bfloat16 row in flight occupies.
 template <>
 struct RowIO<float, 4> {
+  typedef float4 Raw;
+  static __device__ __forceinline__ Raw load_raw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[4]) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
   static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
     float4 t = *reinterpret_cast<const float4*>(p);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -34,12 +39,23 @@ struct RowIO<float, 4> {
 
 template <>
 struct RowIO<float, 1> {
+  typedef float Raw;
+  static __device__ __forceinline__ Raw load_raw(const float* p) { return *p; }
+  static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[1]) { v[0] = t; }
   static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
   static __device__ __forceinline__ void store(float* p, const float (&v)[1]) { *p = v[0]; }
 };
 
 template <>
 struct RowIO<bf16_t, 8> {
+  typedef uint4 Raw;
+  static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[8]) {
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
     uint4 t = *reinterpret_cast<const uint4*>(p);
     v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
@@ -59,6 +75,9 @@ struct RowIO<bf16_t, 8> {
 
 template <>
 struct RowIO<bf16_t, 1> {
+  typedef bf16_t Raw;
+  static __device__ __forceinline__ Raw load_raw(const bf16_t* p) { return *p; }
+  static __device__ __forceinline__ void unpack(const Raw& t, float (&v)[1]) { v[0] = bf16_to_f32(t); }
   static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[1]) { v[0] = bf16_to_f32(*p); }
   static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[1]) { *p = f32_to_bf16(v[0]); }
 };
