@@ -361,6 +361,22 @@ int32_t mpnn_masked_ce(const float* logits, int64_t ld, const int64_t* labels, c
 int32_t mpnn_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                        float* state, float lr, float beta1, float beta2, float eps, mpnn_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * k-nearest-neighbour graph of a batch of equally sized point clouds + normalised distance feature.
+ *
+ * Stands where the reference derives point-cloud edges and the T.Distance(norm=True) feature on the CPU inside
+ * its dataset transforms (experiments/modelnet_exp.py:58, data/dataset.py:193).
+ *   pos        [num_clouds * points, 3] float, clouds stored one after the other
+ *   edge_index [2][num_clouds * points * k] int64: edges j -> i for the k nearest j of each point i of the
+ *              same cloud, grouped by i, ascending distance, ties by lower j
+ *   edge_attr  [num_clouds * points * k] float: distance / largest edge distance of the cloud
+ *   workspace  mpnn_knn_workspace_floats(...) floats
+ * Limits: 1 <= k <= 32, k < points <= 8192.
+ * ------------------------------------------------------------------------- */
+int64_t mpnn_knn_workspace_floats(int32_t num_clouds, int32_t points, int32_t k);
+int32_t mpnn_knn_graph(const float* pos, int32_t num_clouds, int32_t points, int32_t k, int64_t* edge_index,
+                       float* edge_attr, float* workspace, mpnn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,8 @@ class CollateDesc(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/mpnn_amd.h one to one.
 SIGNATURES = {
     "mpnn_collate": (c_int32, [ctypes.POINTER(CollateDesc), c_void_p]),
+    "mpnn_knn_workspace_floats": (c_int64, [c_int32, c_int32, c_int32]),
+    "mpnn_knn_graph": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mpnn_masked_ce_scratch_floats": (c_int64, []),
     "mpnn_masked_ce": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_int64,
                                  c_void_p, c_void_p, c_void_p]),

@@ -25,6 +25,11 @@
 
 namespace mpnn {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// Streams that are read once (index lists, mask words) can bypass the cache hierarchy's retention so that the
+// gathered rows, some of which are re-read often (targets of high in-degree), keep the L2.
+#define NT_LOAD(p) __builtin_nontemporal_load(p)
+
 template <typename T>
 struct FwdArgs {
   const T* A; int64_t ldA;
@@ -85,7 +90,7 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
 #pragma unroll
     for (int f = 0; f < FE; ++f) enx[f] = 0.f;
     if (e0 + lig < e1) {
-      nxt = a.col[e0 + lig];
+      nxt = NT_LOAD(a.col + e0 + lig);
       load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(e0 + lig), a.fe, enx);
     }
     for (int base = e0; base < e1; base += lpr) {
@@ -96,7 +101,7 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
       const int nb = (e1 - base) < lpr ? (e1 - base) : lpr;
       const int pn = base + lpr + lig;
       if (pn < e1) {
-        nxt = a.col[pn];
+        nxt = NT_LOAD(a.col + pn);
         load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)pn, a.fe, enx);
       }
       uint32_t mb[VEC < 4 ? 4 : VEC];  // relu mask words of edge base + lig, collected over the chunk
@@ -144,7 +149,10 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
         if (lig < nb) {
           uint32_t* mp = a.maskbits + (int64_t)(base + lig) * VEC;
 #pragma unroll
-          for (int v = 0; v < VEC; v += 4) *reinterpret_cast<uint4*>(mp + v) = make_uint4(mb[v], mb[v + 1], mb[v + 2], mb[v + 3]);
+          for (int v = 0; v < VEC; v += 4) {
+            u32x4 w4 = {mb[v], mb[v + 1], mb[v + 2], mb[v + 3]};
+            __builtin_nontemporal_store(w4, reinterpret_cast<u32x4*>(mp + v));
+          }
         }
       }
     }
@@ -318,13 +326,13 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a)
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
 
     int nxt = 0, nxtp = 0;
-    if (e0 + lig < e1) { nxt = a.col[e0 + lig]; nxtp = a.tpos[e0 + lig]; }
+    if (e0 + lig < e1) { nxt = NT_LOAD(a.col + e0 + lig); nxtp = NT_LOAD(a.tpos + e0 + lig); }
     for (int base = e0; base < e1; base += lpr) {
       const int cur = nxt, curp = nxtp;
       const int nb = (e1 - base) < lpr ? (e1 - base) : lpr;
       const int pn = base + lpr + lig;
       nxt = 0; nxtp = 0;
-      if (pn < e1) { nxt = a.col[pn]; nxtp = a.tpos[pn]; }
+      if (pn < e1) { nxt = NT_LOAD(a.col + pn); nxtp = NT_LOAD(a.tpos + pn); }
       for (int j = 0; j < nb; j += U) {
         float gv[U][VEC], ev[U][FE];
         uint32_t mw[U][VEC];
@@ -337,7 +345,7 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a)
           const uint32_t* mp = a.maskbits + (int64_t)pp * VEC;
 #pragma unroll
           for (int v = 0; v < VEC; v += 4) {
-            const uint4 w = *reinterpret_cast<const uint4*>(mp + v);
+            const u32x4 w = NT_LOAD(reinterpret_cast<const u32x4*>(mp + v));
             mw[u][v] = w.x;
             if (v + 1 < VEC) mw[u][v + 1] = w.y;
             if (v + 2 < VEC) mw[u][v + 2] = w.z;

@@ -1,0 +1,146 @@
+// k-nearest-neighbour graph of a batch of equally sized point clouds, with the normalised-distance edge
+// feature, built on the device.
+//
+// The reference's point-cloud pipeline derives edges on the CPU inside the dataset transform and attaches
+// T.Distance(norm=True) as the single edge feature (experiments/modelnet_exp.py:58; data/dataset.py:193 turns
+// mesh faces into edges); the benchmark shape for that workload is a k-NN graph (32 clouds x 1024 points, k = 20).
+// Here: edges j -> i for the k nearest j of every point i of the same cloud, listed by target, then by ascending
+// distance, ties by lower source index; edge_attr = distance / (largest edge distance of the cloud).
+//
+// Distances are evaluated as ((dx*dx + dy*dy) + dz*dz) with separately rounded operations (no fused
+// multiply-add), so that the neighbour order is reproducible bit for bit by any IEEE float32 implementation.
+#include <math.h>
+
+#include "common.h"
+
+// every float operation below is rounded on its own: no contraction into fused multiply-adds
+#pragma clang fp contract(off)
+
+namespace mpnn {
+
+constexpr int kKnnMax = 32;        // neighbours tracked per point
+constexpr int kKnnMaxPoints = 8192;  // points per cloud held in LDS (3 floats each)
+
+// K = neighbours tracked per point (>= k), a compile-time size so that the candidate list lives in registers.
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_knn(const float* __restrict__ pos, int points, int k,
+                                                int64_t* __restrict__ edge_index, int64_t num_edges,
+                                                float* __restrict__ dist, unsigned int* __restrict__ cloud_max) {
+  extern __shared__ float cloud[];   // x[points], y[points], z[points]
+  __shared__ float s_max[kBlock];
+  const int c = blockIdx.x;
+  const int64_t base = (int64_t)c * points;
+  float* xs = cloud;
+  float* ys = cloud + points;
+  float* zs = cloud + 2 * points;
+  for (int j = threadIdx.x; j < points; j += kBlock) {
+    xs[j] = pos[(base + j) * 3];
+    ys[j] = pos[(base + j) * 3 + 1];
+    zs[j] = pos[(base + j) * 3 + 2];
+  }
+  __syncthreads();
+  const int i = blockIdx.y * kBlock + threadIdx.x;
+  const int iq = i < points ? i : points - 1;   // surplus lanes shadow the last point and store nothing
+  float bd[K];
+  int bj[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) { bd[t] = INFINITY; bj[t] = 0; }
+  const float xi = xs[iq], yi = ys[iq], zi = zs[iq];
+  for (int j = 0; j < points; ++j) {
+    // plain operators on purpose: the contract(off) pragma above governs them (it does not reach into the
+    // bodies of intrinsic wrappers defined in headers)
+    const float dx = xi - xs[j], dy = yi - ys[j], dz = zi - zs[j];
+    float cd = (dx * dx + dy * dy) + dz * dz;
+    cd = j == iq ? INFINITY : cd;
+    if (!__any(cd < bd[K - 1])) continue;   // wave-uniform: nobody has a use for this candidate
+    int cj = j;
+    // Sorted insert without branches: the candidate takes the place of the first strictly farther entry (so
+    // earlier, lower indices stay ahead at equal distance) and everything from there on moves down one place.
+    bool placed = false;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      placed = placed || cd < bd[t];
+      const float od = bd[t];
+      const int oj = bj[t];
+      bd[t] = placed ? cd : od;
+      bj[t] = placed ? cj : oj;
+      cd = placed ? od : cd;
+      cj = placed ? oj : cj;
+    }
+  }
+  float far = 0.f;
+  if (i < points) {
+    const int64_t e0 = (base + i) * k;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      if (t < k) {
+        const float d = (float)sqrt((double)bd[t]);   // correctly rounded float32 square root
+        edge_index[e0 + t] = base + bj[t];
+        edge_index[num_edges + e0 + t] = base + i;
+        dist[e0 + t] = d;
+        far = fmaxf(far, d);
+      }
+    }
+  }
+  s_max[threadIdx.x] = far;
+  __syncthreads();
+  for (int off = kBlock / 2; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+    __syncthreads();
+  }
+  // distances are non-negative, so their bit patterns order like unsigned integers; max is order-independent
+  if (threadIdx.x == 0) atomicMax(cloud_max + c, __float_as_uint(s_max[0]));
+}
+
+__global__ void __launch_bounds__(kBlock) k_knn_normalise(const float* __restrict__ dist,
+                                                          const unsigned int* __restrict__ cloud_max,
+                                                          int64_t edges_per_cloud, int64_t num_edges,
+                                                          float* __restrict__ edge_attr) {
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= num_edges) return;
+  // float32 quotient, correctly rounded (a double quotient rounds to the same float)
+  edge_attr[e] = (float)((double)dist[e] / (double)__uint_as_float(cloud_max[e / edges_per_cloud]));
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" int32_t mpnn_knn_graph(const float* pos, int32_t num_clouds, int32_t points, int32_t k,
+                                  int64_t* edge_index, float* edge_attr, float* workspace, mpnn_stream_t stream) {
+  if (num_clouds < 0 || points < 2 || k < 1 || k > kKnnMax || k > points - 1 || points > kKnnMaxPoints)
+    return fail(MPNN_E_INVALID, "mpnn_knn_graph: clouds=%d points=%d k=%d (need 1 <= k <= min(%d, points - 1), points <= %d)",
+                num_clouds, points, k, kKnnMax, kKnnMaxPoints);
+  if (num_clouds == 0) return MPNN_OK;
+  if (!pos || !edge_index || !edge_attr || !workspace) return fail(MPNN_E_INVALID, "mpnn_knn_graph: null pointer argument");
+  const int64_t num_edges = (int64_t)num_clouds * points * k;
+  if (num_edges >= INT32_MAX) return fail(MPNN_E_INVALID, "mpnn_knn_graph: more than 2^31 edges");
+  // workspace: [num_edges] distances, then [num_clouds] per-cloud maxima
+  float* dist = workspace;
+  unsigned int* cloud_max = reinterpret_cast<unsigned int*>(workspace + num_edges);
+  MPNN_HIP_CHECK(hipMemsetAsync(cloud_max, 0, (size_t)num_clouds * sizeof(unsigned int), stream));
+  const size_t lds = (size_t)3 * points * sizeof(float);
+  dim3 grid(num_clouds, (points + kBlock - 1) / kBlock);
+  auto launch = [&](auto kern) -> int32_t {
+    if (lds > 48 * 1024)
+      MPNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    kern<<<grid, kBlock, lds, stream>>>(pos, points, k, edge_index, num_edges, dist, cloud_max);
+    return MPNN_OK;
+  };
+  int32_t rc;
+  if (k <= 8) rc = launch(k_knn<8>);
+  else if (k <= 16) rc = launch(k_knn<16>);
+  else if (k <= 24) rc = launch(k_knn<24>);
+  else rc = launch(k_knn<32>);
+  if (rc != MPNN_OK) return rc;
+  MPNN_LAUNCH_CHECK("k_knn");
+  k_knn_normalise<<<(unsigned)((num_edges + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dist, cloud_max, (int64_t)points * k,
+                                                                                       num_edges, edge_attr);
+  MPNN_LAUNCH_CHECK("k_knn_normalise");
+  return MPNN_OK;
+}
+
+extern "C" int64_t mpnn_knn_workspace_floats(int32_t num_clouds, int32_t points, int32_t k) {
+  if (num_clouds < 0 || points < 0 || k < 0) return -1;
+  return (int64_t)num_clouds * points * k + num_clouds;
+}

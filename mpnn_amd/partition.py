@@ -72,6 +72,30 @@ class PartitionedGraph:
         return t[self.edge_ids]
 
 
+def _via_host(t: torch.Tensor, group) -> bool:
+    """gloo moves host memory: device tensors are staged through the CPU (rehearsals of the multi-rank path on
+    one GPU, or hosts without RCCL); with the nccl backend (RCCL) tensors go device to device."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_gather_into(out: torch.Tensor, send: torch.Tensor, group) -> None:
+    if _via_host(send, group):
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, send.cpu(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, send, group=group)
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> None:
+    if _via_host(t, group):
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
 class _HaloAllGather(torch.autograd.Function):
     """[n_local, H] -> [world * n_pad, H]; the backward returns each owner the sum of what all ranks computed."""
 
@@ -83,21 +107,21 @@ class _HaloAllGather(torch.autograd.Function):
             send = b_local.new_zeros((n_pad, h))
             send[:n_local] = b_local
         out = b_local.new_empty((world * n_pad, h))
-        dist.all_gather_into_tensor(out, send, group=group)
+        _all_gather_into(out, send, group)
         ctx.n_local, ctx.n_pad, ctx.group = n_local, n_pad, group
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        out = g.new_empty((ctx.n_pad, g.size(1)))
-        try:
-            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=ctx.group)
-        except RuntimeError:
-            # backends without reduce-scatter (gloo): all-reduce, then keep the own slice
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)
+        if dist.get_backend(ctx.group) == "gloo":
+            # gloo has no reduce-scatter: all-reduce, then keep the own slice
+            _all_reduce_sum(g, ctx.group)
             r = dist.get_rank(ctx.group)
             out = g[r * ctx.n_pad:(r + 1) * ctx.n_pad]
+        else:
+            out = g.new_empty((ctx.n_pad, g.size(1)))
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=ctx.group)
         return out[:ctx.n_local], None, None, None
 
 
@@ -144,7 +168,7 @@ def allreduce_gradients(module: torch.nn.Module, group=None, average: bool = Fal
         if p.grad is None:
             p.grad = torch.zeros_like(p)
     flat = torch.cat([p.grad.reshape(-1).float() for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce_sum(flat, group)
     if average:
         flat /= dist.get_world_size(group)
     off = 0

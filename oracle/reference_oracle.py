@@ -296,3 +296,27 @@ def adam_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8):
     step_size = lr / (1 - beta1 ** t)
     denom = v.sqrt() / (1 - beta2 ** t) ** 0.5 + eps
     return p - step_size * (m / denom), m, v
+
+
+# ----------------------------------------------------------------------------
+# k-NN graph of point clouds with the normalised distance feature
+# ----------------------------------------------------------------------------
+def knn_graph(pos: torch.Tensor, num_clouds: int, k: int):
+    """Edges j -> i for the k nearest j of each point i of the same cloud (grouped by i, ascending distance, ties
+    by lower j) and T.Distance(norm=True)'s feature (experiments/modelnet_exp.py:58): distance divided by the
+    largest edge distance of the cloud.  float32, squared distance as ((dx*dx + dy*dy) + dz*dz)."""
+    pts = pos.view(num_clouds, -1, 3).float()
+    p = pts.size(1)
+    src, dst, attr = [], [], []
+    for c in range(num_clouds):
+        d = pts[c][:, None, :] - pts[c][None, :, :]          # [i, j, 3] = p_i - p_j
+        d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+        d2.fill_diagonal_(float("inf"))
+        val, idx = torch.sort(d2, dim=1, stable=True)
+        # correctly rounded float32 square root and quotient, obtained by rounding the float64 results (torch's
+        # float32 CPU sqrt is a few-ulp approximation, and division by a 0-dim tensor multiplies by a reciprocal)
+        dist = torch.sqrt(val[:, :k].double()).float()
+        src.append(idx[:, :k].reshape(-1) + c * p)
+        dst.append(torch.arange(p).repeat_interleave(k) + c * p)
+        attr.append((dist.double() / dist.max().double()).float().reshape(-1))
+    return torch.stack([torch.cat(src), torch.cat(dst)]), torch.cat(attr).view(-1, 1)

@@ -1,0 +1,73 @@
+"""Dataset stand-ins keep the reference's method names (data/dataset.py) and feed its training loops."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+def test_wrappers_expose_the_reference_method_names():
+    import inspect
+    from mpnn_amd import datasets
+    assert {"get_data", "get_split"} <= set(dir(datasets.FlickrDataset))
+    assert {"get_loader", "get_full_graphs", "get_data"} <= set(dir(datasets.QM9Dataset))
+    assert {"get_loaders", "get_full_graphs"} <= set(dir(datasets.ModelNetDataset))
+    assert list(inspect.signature(datasets.QM9Dataset.get_loader).parameters)[:3] == ["self", "batch_size", "shuffle"]
+    assert list(inspect.signature(datasets.ModelNetDataset.get_loaders).parameters) == ["self", "batch_size", "shuffle"]
+    assert datasets._split_sizes(1001) == (800, 100, 101)
+
+
+@pytest.mark.gpu
+def test_qm9_training_loop_as_the_reference_writes_it():
+    """training/train.py:85-98 (Train_QM9) with the stand-in dataset, the drop-in trainer and model."""
+    from mpnn_amd import MPNN_QM9
+    from mpnn_amd.datasets import QM9Dataset
+    from mpnn_amd.optim import FlatAdam
+    from mpnn_amd.train import Trainer_QM9
+    ds = QM9Dataset(num_graphs=300)
+    train_loader, val_loader, test_loader = ds.get_loader(batch_size=64)
+    assert (len(train_loader), len(val_loader), len(test_loader)) == (4, 1, 1)
+    torch.manual_seed(0)
+    model = MPNN_QM9(11, 4, 32, 19, num_layers=2, mode="sum").cuda()
+    trainer = Trainer_QM9(model, FlatAdam(model.parameters(), lr=1e-2), F.mse_loss, "cuda")
+    first = last = None
+    for epoch in range(3):
+        loss = 0.0
+        for data in train_loader:
+            data.to("cuda")
+            loss += trainer.train(data)
+        first = loss if first is None else first
+        last = loss
+    assert last == last and last < first * 1.5          # finite, not diverging
+    test_loss = sum(trainer.test(data) for data in test_loader)
+    assert test_loss == test_loss
+    full = ds.get_full_graphs()
+    assert [b.num_graphs for b in full] == [240, 30, 30]
+    assert trainer.test(full[2]) == trainer.test(full[2])
+
+
+@pytest.mark.gpu
+def test_modelnet_and_flickr_stand_ins():
+    from mpnn_amd import MPNN, MPNN_ModelNet
+    from mpnn_amd.datasets import FlickrDataset, ModelNetDataset
+    from mpnn_amd.optim import FlatAdam
+    from mpnn_amd.train import Trainer_Flickr, Trainer_ModelNet
+    ds = ModelNetDataset(train_clouds=12, test_clouds=4, points=128, k=8)
+    train_loader, test_loader = ds.get_loaders(batch_size=4)
+    model = MPNN_ModelNet(3, 1, 32, 10, num_layers=2, mode="cat").cuda()
+    trainer = Trainer_ModelNet(model, FlatAdam(model.parameters(), lr=1e-2), F.cross_entropy, "cuda")
+    losses = [trainer.train(data) for data in train_loader]
+    assert len(losses) == 3 and all(l == l for l in losses)
+    assert all(t == t for t in (trainer.test(d) for d in test_loader))
+    data = ds.get_full_graphs()[0]
+    assert data.num_graphs == 12 and data.edge_index.shape == (2, 12 * 128 * 8) and data.edge_attr.shape == (12 * 128 * 8, 1)
+
+    fl = FlickrDataset(num_nodes=2000, num_edges=12000, num_features=40)
+    d = fl.get_data()
+    tr, va, te = fl.get_split()
+    assert int((tr | va | te).sum()) == 2000 and int((tr & va).sum()) == 0 and int((va & te).sum()) == 0
+    assert d.edge_attr.shape == (12000, 4) and bool((d.edge_attr == 1).all())
+    m = MPNN(40, 32, 7, num_layers=2, mode="sum").cuda()
+    t = Trainer_Flickr(m, FlatAdam(m.parameters(), lr=1e-2), F.cross_entropy, "cuda")
+    l0 = t.train(d)
+    for _ in range(5):
+        l1 = t.train(d)
+    assert l1 < l0 and 0.0 <= t.test(d) <= 1.0
