@@ -15,6 +15,10 @@
 // The TN form reduces over rows: each block walks a strided set of 32-row slabs, keeps a 128x128 output
 // tile in accumulators and writes one partial tile; partials are summed in slab order by
 // k_sum_partials (fixed order, no atomics).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace mpnn {
@@ -86,22 +90,65 @@ __device__ __forceinline__ float4 relu_mask4(float4 v, float4 m) {
 // owns 4 consecutive output columns of one row per register quad and the epilogue moves 16 bytes per access.
 // That pays when the epilogue also reads emul and writes Y2 (three arrays); for a single output the
 // 4-byte, whole-line pattern of the plain layout is faster.
-template <int MT, int WC, bool ALIGNED, bool TRANS>
-__global__ void __launch_bounds__(kBlock * WC) k_gemm_nt(NtArgs a) {
+//
+// SPLIT computes the same float32 products on the bfloat16 matrix cores, which run 16 times the rate of the
+// float32 ones: every operand value v is written to LDS as three bfloat16 pieces v = v1 + v2 + v3 (v1 = bf16(v),
+// v2 = bf16(v - v1), v3 = bf16(v - v1 - v2); the three 8-bit significands hold all 24 bits of v, the sum is
+// exact), and a product x*w is accumulated in float32 as x3*w1 + x1*w3 + x2*w2 + x2*w1 + x1*w2 + x1*w1 - the
+// dropped terms are below 2^-32 of |x*w|.  Each piece product is exact in float32, so the result carries float32
+// rounding of the accumulation only (measured: error against float64 no larger than the float32 MFMA's).
+// k-chunks are 16 wide (one v_mfma_f32_32x32x16_bf16 step); an LDS row is 3 pieces x 16 k x 2 B + 16 B pad.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Stand-in "mask" of an unmasked segment inside a kernel compiled with mask support: every lane reads these
+// 16 bytes (a cache hit), which keeps the load sequence of a chunk free of branches.
+__device__ const float kOnes[4] = {1.f, 1.f, 1.f, 1.f};
+
+constexpr int kSplitBK = 16;
+constexpr int kSplitRowB = 3 * kSplitBK * 2 + 16;   // 112 bytes = 7 sixteen-byte slots (odd => conflict-free b128)
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  const bf16x2 b = __builtin_convertvector(v, bf16x2);   // round to nearest even, one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, b);
+}
+
+// The three bfloat16 pieces of 4 consecutive floats, each as 4 packed values (8 bytes).
+__device__ __forceinline__ void split4(float4 v, uint2 (&p)[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    p[i].x = pack_bf16(v.x, v.y);
+    p[i].y = pack_bf16(v.z, v.w);
+    if (i < 2) {   // remainders are exact in float32
+      v.x -= __uint_as_float(p[i].x << 16); v.y -= __uint_as_float(p[i].x & 0xffff0000u);
+      v.z -= __uint_as_float(p[i].y << 16); v.w -= __uint_as_float(p[i].y & 0xffff0000u);
+    }
+  }
+}
+
+template <int MT, int WC, bool ALIGNED, bool TRANS, bool SPLIT, bool MASKED>
+__global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
+  static_assert(!SPLIT || ALIGNED, "the split form needs 16-byte aligned rows");
   constexpr int NTHREADS = kBlock * WC;
   constexpr int WROWS = 32 * MT * WC;
-  constexpr int XQ = (kBN * (kBK / 4)) / NTHREADS;                   // float4 of X per thread and chunk
-  constexpr int WQ = (WROWS * (kBK / 4) + NTHREADS - 1) / NTHREADS;  // float4 of W per thread and chunk
-  constexpr int STAGE = (kBN + WROWS) * kLd;
+  constexpr int BK = SPLIT ? kSplitBK : kBK;
+  constexpr int QPR = BK / 4;                                       // float4 per row and chunk
+  constexpr int XQ = (kBN * QPR) / NTHREADS;                        // float4 of X per thread and chunk
+  constexpr int WQ = (WROWS * QPR + NTHREADS - 1) / NTHREADS;       // float4 of W per thread and chunk
+  constexpr int ROWB = SPLIT ? kSplitRowB : kLd * 4;                // bytes per LDS row
+  constexpr int STAGEB = (kBN + WROWS) * ROWB;
   extern __shared__ float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int wr = wid & 3, wc = wid >> 2;
   const int li = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.y * WROWS;
-  const int nch0 = (a.seg[0].K + kBK - 1) / kBK;
-  const int nch = nch0 + (a.nseg > 1 ? (a.seg[1].K + kBK - 1) / kBK : 0);
+  const int nch0 = (a.seg[0].K + BK - 1) / BK;
+  const int nch = nch0 + (a.nseg > 1 ? (a.seg[1].K + BK - 1) / BK : 0);
 
   // The (row step, k-chunk) pairs of this block form one flat sequence, so the first chunk of the next
   // row step is already in flight while the last chunk of the current one is multiplied and stored.
@@ -114,82 +161,158 @@ __global__ void __launch_bounds__(kBlock * WC) k_gemm_nt(NtArgs a) {
   for (int c = 0; c < MT; ++c)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
-  float4 xr[XQ], mr[XQ], wreg[WQ];
-  int xv[XQ], wv[WQ];
-  bool masked = false;
 
-  auto fetch = [&](int64_t row0, int c) {
+  // Loads of X (HBM) run D - 1 chunks ahead of the multiply: a ring of D register sets (set i % D holds chunk i).
+  // With the narrow chunks of the split form one chunk ahead covers only a fraction of the memory latency.
+  // The weight tile comes out of the L2 and runs two chunks ahead in a ring of 2 sets (set = chunk parity).  Loads
+  // return in issue order, so within an iteration the weight load is issued BEFORE the X load: waiting for the
+  // weights of chunk i + 1 then leaves the younger X loads in flight.
+  constexpr int D = (SPLIT && !MASKED) ? 4 : 2;   // mask operands double the registers of a set
+  float4 xr[D][XQ], mr[MASKED ? D : 1][XQ], wreg[2][WQ];
+  int xk[D], xK[D], wk[2], wK[2];   // k origin and row length of the chunk a set holds (for the tail mask)
+  bool masked[D];
+  int64_t f_row0 = (int64_t)blockIdx.x * kBN;   // position of the next X fetch in the (row step, chunk) sequence
+  int f_c = 0;
+
+  auto fetch = [&](auto S) {
+    constexpr int st = decltype(S)::value;
+    const int c = f_c;
+    const int64_t row0 = f_row0;
+    if (++f_c == nch) { f_c = 0; f_row0 += (int64_t)gridDim.x * kBN; }
     const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
-    const int k0 = (c < nch0 ? c : c - nch0) * kBK;
-    masked = sg.mask != nullptr;
+    const int k0 = (c < nch0 ? c : c - nch0) * BK;
+    masked[st] = MASKED && sg.mask != nullptr;
+    xk[st] = k0;
+    xK[st] = sg.K;
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
       const int idx = tid + NTHREADS * q;
-      const int c4 = (idx & 7) * 4;
-      int64_t row = row0 + (idx >> 3);
+      const int c4 = (idx % QPR) * 4;
+      int64_t row = row0 + idx / QPR;
       row = row < a.N ? row : a.N - 1;   // rows past the end compute garbage that is never stored
-      xr[q] = load_chunk4<ALIGNED>(sg.X + row * sg.ldx, k0 + c4, sg.K);
-      if (masked) mr[q] = load_chunk4<ALIGNED>(sg.mask + row * sg.ldm, k0 + c4, sg.K);
-      xv[q] = valid4(k0 + c4, sg.K, true);
-    }
-#pragma unroll
-    for (int q = 0; q < WQ; ++q) {
-      const int idx = tid + NTHREADS * q;
-      const int c4 = (idx & 7) * 4;
-      int r = m0 + (idx >> 3);
-      r = r < a.M ? r : a.M - 1;
-      wreg[q] = load_chunk4<ALIGNED>(sg.W + (int64_t)r * sg.ldw, k0 + c4, sg.K);
-      wv[q] = valid4(k0 + c4, sg.K, true);
+      xr[st][q] = load_chunk4<ALIGNED>(sg.X + row * sg.ldx, k0 + c4, sg.K);
+      if constexpr (MASKED) {
+        const float* mp = masked[st] ? sg.mask + row * sg.ldm : kOnes;
+        mr[st][q] = load_chunk4<ALIGNED>(mp, masked[st] ? k0 + c4 : 0, masked[st] ? sg.K : 4);
+      }
     }
   };
-  auto stash = [&](int buf) {
-    float* Xs = lds + buf * STAGE;
-    float* Ws = Xs + kBN * kLd;
+  auto fetch_w = [&](auto P, int c) {
+    constexpr int ws = decltype(P)::value;
+    const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
+    wk[ws] = (c < nch0 ? c : c - nch0) * BK;
+    wK[ws] = sg.K;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      int r = m0 + idx / QPR;
+      r = r < a.M ? r : a.M - 1;
+      wreg[ws][q] = load_chunk4<ALIGNED>(sg.W + (int64_t)r * sg.ldw, wk[ws] + (idx % QPR) * 4, sg.K);
+    }
+  };
+  auto put = [&](char* tile, int idx, float4 v) {
+    char* dst = tile + (idx / QPR) * ROWB;
+    if constexpr (SPLIT) {
+      uint2 p[3];
+      split4(v, p);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(dst + i * (kSplitBK * 2) + (idx % QPR) * 8) = p[i];
+    } else {
+      *reinterpret_cast<float4*>(dst + (idx % QPR) * 16) = v;
+    }
+  };
+  auto stash = [&](auto S, int buf) {
+    constexpr int st = decltype(S)::value;
+    char* Xs = ldsb + buf * STAGEB;
+    char* Ws = Xs + kBN * ROWB;
+    constexpr int ws = st & 1;
+    const bool x_tail = xk[st] + BK > xK[st], w_tail = wk[ws] + BK > wK[ws];   // uniform: only a row's last chunk masks
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
       const int idx = tid + NTHREADS * q;
-      float4 v = select4(xr[q], xv[q]);
-      if (masked) v = relu_mask4(v, mr[q]);  // relu backward fused into the operand
-      *reinterpret_cast<float4*>(Xs + (idx >> 3) * kLd + (idx & 7) * 4) = v;
+      float4 v = xr[st][q];
+      if (x_tail) v = select4(v, valid4(xk[st] + (idx % QPR) * 4, xK[st], true));
+      if constexpr (MASKED) v = relu_mask4(v, mr[st][q]);  // relu backward fused into the operand (ones if unmasked)
+      put(Xs, idx, v);
     }
 #pragma unroll
     for (int q = 0; q < WQ; ++q) {
       const int idx = tid + NTHREADS * q;
-      if ((idx >> 3) < WROWS)
-        *reinterpret_cast<float4*>(Ws + (idx >> 3) * kLd + (idx & 7) * 4) = select4(wreg[q], wv[q]);
+      float4 v = wreg[ws][q];
+      if (w_tail) v = select4(v, valid4(wk[ws] + (idx % QPR) * 4, wK[ws], true));
+      if (idx / QPR < WROWS) put(Ws, idx, v);
     }
   };
 
-  if (total > 0) {
-    fetch((int64_t)blockIdx.x * kBN, 0);
-    stash(0);
-  }
-  __syncthreads();
   int64_t step = 0;
   int c = 0;
-  for (int64_t it = 0; it < total; ++it) {
+  // one chunk: start the load of chunk it + D - 1 (into the set chunk it - 1 has just left), multiply chunk it out
+  // of LDS buffer it & 1, store the tile at the end of a row step, then move chunk it + 1 from its registers
+  // into the other LDS buffer
+  auto body = [&](auto S, int64_t it) {
+    constexpr int st = decltype(S)::value;            // == it % D
+    using Prev = std::integral_constant<int, (st + D - 1) % D>;
+    using Next = std::integral_constant<int, (st + 1) % D>;
     const int buf = (int)(it & 1);
     const int64_t row0 = (blockIdx.x + step * gridDim.x) * kBN;
     const bool last_chunk = c + 1 == nch;
-    if (it + 1 < total) fetch(last_chunk ? row0 + (int64_t)gridDim.x * kBN : row0, last_chunk ? 0 : c + 1);
-    const float* Xs = lds + buf * STAGE;
-    const float* Ws = Xs + kBN * kLd;
-#pragma unroll
-    for (int kq = 0; kq < kBK / 8; ++kq) {
-      const float4 av = *reinterpret_cast<const float4*>(Xs + (wr * 32 + li) * kLd + kq * 8 + lh * 4);
+    // Both loads are issued unconditionally (past the end of the block's work they re-read valid rows and are
+    // never used): a load under a branch makes the compiler wait for EVERY outstanding load at the next use,
+    // which would drain the ring each chunk.
+    {
+      int cw = c + 2;
+      while (cw >= nch) cw -= nch;
+      fetch_w(std::integral_constant<int, st & 1>{}, cw);
+    }
+    fetch(Prev{});
+    const char* Xs = ldsb + buf * STAGEB;
+    const char* Ws = Xs + kBN * ROWB;
+    if constexpr (SPLIT) {
+      // lane (li, lh) holds k = 8 lh .. 8 lh + 7 of row li of each piece: one 16-byte read per piece
+      const char* xrow = Xs + (wr * 32 + li) * ROWB + lh * 16;
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(xrow);
+      const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(xrow + 2 * kSplitBK);
+      const bf16x8 a3 = *reinterpret_cast<const bf16x8*>(xrow + 4 * kSplitBK);
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
-        const float4 bv = *reinterpret_cast<const float4*>(Ws + ((wc * MT + t) * 32 + li) * kLd + kq * 8 + lh * 4);
+        const char* wrow = Ws + ((wc * MT + t) * 32 + li) * ROWB + lh * 16;
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wrow);
+        const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wrow + 2 * kSplitBK);
+        const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wrow + 4 * kSplitBK);
         if (TRANS) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[t], 0, 0, 0);
         } else {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kq = 0; kq < kBK / 8; ++kq) {
+        const float4 av = *reinterpret_cast<const float4*>(Xs + (wr * 32 + li) * ROWB + (kq * 8 + lh * 4) * 4);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float4 bv = *reinterpret_cast<const float4*>(Ws + ((wc * MT + t) * 32 + li) * ROWB + (kq * 8 + lh * 4) * 4);
+          if (TRANS) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, acc[t], 0, 0, 0);
+          } else {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
+          }
         }
       }
     }
@@ -243,8 +366,28 @@ __global__ void __launch_bounds__(kBlock * WC) k_gemm_nt(NtArgs a) {
     } else {
       ++c;
     }
-    if (it + 1 < total) stash(buf ^ 1);
+    if (it + 1 < total) stash(Next{}, buf ^ 1);
     __syncthreads();
+  };
+
+  // prologue: chunks 0 .. D-2 in flight, chunk 0 in LDS
+  if (total == 0) return;   // uniform over the block
+  fetch_w(std::integral_constant<int, 0>{}, 0);
+  fetch(std::integral_constant<int, 0>{});
+  fetch_w(std::integral_constant<int, 1>{}, 1 % nch);
+  if constexpr (D > 2) {
+    fetch(std::integral_constant<int, 1>{});
+    fetch(std::integral_constant<int, 2>{});
+  }
+  stash(std::integral_constant<int, 0>{}, 0);
+  __syncthreads();
+  for (int64_t it = 0; it < total; it += D) {
+    body(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
+    if constexpr (D > 2) {
+      if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
+      if (it + 3 < total) body(std::integral_constant<int, 3>{}, it + 3);
+    }
   }
 }
 
@@ -378,6 +521,13 @@ static int tn_slabs(int64_t N, int M, int K) {
   return (int)slabs;
 }
 
+// MPNN_GEMM=f32 selects the float32 matrix-core instructions; the default is the 3-piece bfloat16 split form.
+// Read on every call (one getenv) so that a test can compare the two forms inside one process.
+static bool gemm_split() {
+  const char* e = getenv("MPNN_GEMM");
+  return !(e && (e[0] == 'f' || e[0] == 'F'));
+}
+
 static bool nt_aligned(const NtArgs& a) {
   for (int s = 0; s < a.nseg; ++s) {
     const NtSegment& g = a.seg[s];
@@ -393,16 +543,24 @@ static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
   if (blocks > 1024) blocks = 1024;
   constexpr int WROWS = 32 * MT * WC;
   dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
-  const size_t lds = (size_t)2 * (kBN + WROWS) * kLd * sizeof(float);
   // transposed accumulator tile only for the three-array epilogue, and only when 16-byte accesses are legal
   const bool trans = a.Y2 && (a.M & 3) == 0 && ((a.ldy | a.ldy2 | a.ldemul) & 3) == 0 &&
                      (((uintptr_t)a.Y | (uintptr_t)a.Y2 | (uintptr_t)a.emul) & 15) == 0;
+  const bool has_mask = a.seg[0].mask || (a.nseg > 1 && a.seg[1].mask);
+  auto go = [&](auto kern, size_t lds) { kern<<<grid, kBlock * WC, lds, stream>>>(a); };
+  if (aligned && gemm_split()) {
+    const size_t lds = (size_t)2 * (kBN + WROWS) * kSplitRowB;
+    if (trans) has_mask ? go(k_gemm_nt<MT, WC, true, true, true, true>, lds) : go(k_gemm_nt<MT, WC, true, true, true, false>, lds);
+    else has_mask ? go(k_gemm_nt<MT, WC, true, false, true, true>, lds) : go(k_gemm_nt<MT, WC, true, false, true, false>, lds);
+    return;
+  }
+  const size_t lds = (size_t)2 * (kBN + WROWS) * kLd * sizeof(float);
   if (trans) {
-    if (aligned) k_gemm_nt<MT, WC, true, true><<<grid, kBlock * WC, lds, stream>>>(a);
-    else k_gemm_nt<MT, WC, false, true><<<grid, kBlock * WC, lds, stream>>>(a);
+    if (aligned) go(k_gemm_nt<MT, WC, true, true, false, true>, lds);
+    else go(k_gemm_nt<MT, WC, false, true, false, true>, lds);
   } else {
-    if (aligned) k_gemm_nt<MT, WC, true, false><<<grid, kBlock * WC, lds, stream>>>(a);
-    else k_gemm_nt<MT, WC, false, false><<<grid, kBlock * WC, lds, stream>>>(a);
+    if (aligned) go(k_gemm_nt<MT, WC, true, false, false, true>, lds);
+    else go(k_gemm_nt<MT, WC, false, false, false, true>, lds);
   }
 }
 

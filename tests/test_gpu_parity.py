@@ -373,3 +373,28 @@ def test_recomputing_backward_matches_mask_bit_backward(dev):
         ops.USE_MASKBITS = True
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k1,k2,m", [(5000, 128, 0, 128), (3000, 128, 256, 128), (2000, 500, 64, 64), (4096, 64, 0, 256)])
+def test_split_bf16_gemm_is_as_accurate_as_the_float32_matrix_cores(n, k1, k2, m, monkeypatch):
+    """The default NT GEMM multiplies on the bfloat16 matrix cores with every float32 operand split into three
+    bfloat16 pieces; against a float64 product its error must not exceed the float32-MFMA form's by more than a
+    small factor, and both must sit at float32 rounding level (far inside the 1e-5 parity bar)."""
+    from mpnn_amd.dense import gemm_nt
+    g = torch.Generator().manual_seed(n + m)
+    x1 = torch.randn(n, k1, generator=g)
+    w1 = torch.randn(m, k1, generator=g) / k1 ** 0.5
+    x2 = torch.randn(n, k2, generator=g) if k2 else None
+    w2 = torch.randn(m, k2, generator=g) / k2 ** 0.5 if k2 else None
+    ref = x1.double() @ w1.double().t()
+    if k2:
+        ref = ref + x2.double() @ w2.double().t()
+    cu = lambda t: t.cuda() if t is not None else None
+    err = {}
+    for mode in ("split", "f32"):
+        monkeypatch.setenv("MPNN_GEMM", mode)
+        y = gemm_nt(cu(x1), cu(w1), cu(x2), cu(w2)).cpu().double()
+        err[mode] = float((y - ref).abs().max() / ref.abs().max())
+    assert err["f32"] < 2e-6 and err["split"] < 2e-6, err
+    assert err["split"] <= 2.0 * err["f32"] + 1e-7, err
