@@ -184,16 +184,39 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
     masked[st] = MASKED && sg.mask != nullptr;
     xk[st] = k0;
     xK[st] = sg.K;
+    if constexpr (ALIGNED) {
+      // uniform base pointer + a 32-bit per-thread offset: the loads take the scalar-base addressing form and
+      // cost no per-thread 64-bit arithmetic.  Rows past the end re-read the last row (never stored).
+      const int64_t left = a.N - 1 - row0;
+      const int rt_max = left < kBN - 1 ? (left < 0 ? 0 : (int)left) : kBN - 1;
+      const int64_t rbase = row0 <= a.N - 1 ? row0 : a.N - 1;
+      const float* xb = sg.X + rbase * sg.ldx;
+      const float* mb = masked[st] ? sg.mask + rbase * sg.ldm : kOnes;
+      const uint32_t ldx = (uint32_t)sg.ldx, ldm = masked[st] ? (uint32_t)sg.ldm : 0u;
+      const bool tail = k0 + BK > sg.K;
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-      const int idx = tid + NTHREADS * q;
-      const int c4 = (idx % QPR) * 4;
-      int64_t row = row0 + idx / QPR;
-      row = row < a.N ? row : a.N - 1;   // rows past the end compute garbage that is never stored
-      xr[st][q] = load_chunk4<ALIGNED>(sg.X + row * sg.ldx, k0 + c4, sg.K);
-      if constexpr (MASKED) {
-        const float* mp = masked[st] ? sg.mask + row * sg.ldm : kOnes;
-        mr[st][q] = load_chunk4<ALIGNED>(mp, masked[st] ? k0 + c4 : 0, masked[st] ? sg.K : 4);
+      for (int q = 0; q < XQ; ++q) {
+        const int idx = tid + NTHREADS * q;
+        int kk = k0 + (idx % QPR) * 4;
+        if (tail) kk = kk < sg.K ? kk : sg.K - 4;
+        int rt = idx / QPR;
+        rt = rt < rt_max ? rt : rt_max;
+        xr[st][q] = *reinterpret_cast<const float4*>(xb + ((uint32_t)rt * ldx + (uint32_t)kk));
+        if constexpr (MASKED)
+          mr[st][q] = *reinterpret_cast<const float4*>(mb + ((uint32_t)rt * ldm + (masked[st] ? (uint32_t)kk : 0u)));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        const int idx = tid + NTHREADS * q;
+        const int c4 = (idx % QPR) * 4;
+        int64_t row = row0 + idx / QPR;
+        row = row < a.N ? row : a.N - 1;   // rows past the end compute garbage that is never stored
+        xr[st][q] = load_chunk4<ALIGNED>(sg.X + row * sg.ldx, k0 + c4, sg.K);
+        if constexpr (MASKED) {
+          const float* mp = masked[st] ? sg.mask + row * sg.ldm : kOnes;
+          mr[st][q] = load_chunk4<ALIGNED>(mp, masked[st] ? k0 + c4 : 0, masked[st] ? sg.K : 4);
+        }
       }
     }
   };
@@ -202,12 +225,28 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
     const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
     wk[ws] = (c < nch0 ? c : c - nch0) * BK;
     wK[ws] = sg.K;
+    if constexpr (ALIGNED) {
+      const int r_max = a.M - 1 - m0 < WROWS - 1 ? a.M - 1 - m0 : WROWS - 1;
+      const float* wb = sg.W + (int64_t)m0 * sg.ldw;
+      const uint32_t ldw = (uint32_t)sg.ldw;
+      const bool tail = wk[ws] + BK > sg.K;
 #pragma unroll
-    for (int q = 0; q < WQ; ++q) {
-      const int idx = tid + NTHREADS * q;
-      int r = m0 + idx / QPR;
-      r = r < a.M ? r : a.M - 1;
-      wreg[ws][q] = load_chunk4<ALIGNED>(sg.W + (int64_t)r * sg.ldw, wk[ws] + (idx % QPR) * 4, sg.K);
+      for (int q = 0; q < WQ; ++q) {
+        const int idx = tid + NTHREADS * q;
+        int kk = wk[ws] + (idx % QPR) * 4;
+        if (tail) kk = kk < sg.K ? kk : sg.K - 4;
+        int r = idx / QPR;
+        r = r < r_max ? r : r_max;
+        wreg[ws][q] = *reinterpret_cast<const float4*>(wb + ((uint32_t)r * ldw + (uint32_t)kk));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) {
+        const int idx = tid + NTHREADS * q;
+        int r = m0 + idx / QPR;
+        r = r < a.M ? r : a.M - 1;
+        wreg[ws][q] = load_chunk4<ALIGNED>(sg.W + (int64_t)r * sg.ldw, wk[ws] + (idx % QPR) * 4, sg.K);
+      }
     }
   };
   auto put = [&](char* tile, int idx, float4 v) {
@@ -346,19 +385,40 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
       c = 0;
     } else if (last_chunk) {
       // C layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-      for (int t = 0; t < MT; ++t) {
-        const int col = m0 + (wc * MT + t) * 32 + li;
+      constexpr bool WITH_Y2 = !SPLIT;   // the split form leaves a second output to the transposed variant
+      const bool interior = row0 + kBN <= a.N && m0 + WROWS <= a.M;   // uniform over the block
+      if (interior && !(WITH_Y2 && a.Y2)) {
+        // whole tile inside the matrix: one running row pointer, the MT column tiles at immediate offsets
+        float* p = a.Y + (row0 + wr * 32 + 4 * lh) * a.ldy + (m0 + wc * MT * 32 + li);
+        const bool relu = a.relu != 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (col < a.M && row < a.N) {
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
             float v = acc[t][r];
-            if (a.relu) v = v <= 0.f ? 0.f : v;
-            a.Y[row * a.ldy + col] = v;
-            if (a.Y2) a.Y2[row * a.ldy2 + col] = v * a.emul[row * a.ldemul + col];
+            v = (relu && v <= 0.f) ? 0.f : v;
+            p[t * 32] = v;
+            acc[t][r] = 0.f;
           }
-          acc[t][r] = 0.f;
+          p += ((r & 3) == 3 ? 5 : 1) * a.ldy;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const int col = m0 + (wc * MT + t) * 32 + li;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (col < a.M && row < a.N) {
+              float v = acc[t][r];
+              if (a.relu) v = v <= 0.f ? 0.f : v;
+              a.Y[row * a.ldy + col] = v;
+              if constexpr (WITH_Y2) {
+                if (a.Y2) a.Y2[row * a.ldy2 + col] = v * a.emul[row * a.ldemul + col];
+              }
+            }
+            acc[t][r] = 0.f;
+          }
         }
       }
       ++step;
@@ -548,7 +608,7 @@ static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
                      (((uintptr_t)a.Y | (uintptr_t)a.Y2 | (uintptr_t)a.emul) & 15) == 0;
   const bool has_mask = a.seg[0].mask || (a.nseg > 1 && a.seg[1].mask);
   auto go = [&](auto kern, size_t lds) { kern<<<grid, kBlock * WC, lds, stream>>>(a); };
-  if (aligned && gemm_split()) {
+  if (aligned && gemm_split() && (trans || !a.Y2)) {
     const size_t lds = (size_t)2 * (kBN + WROWS) * kSplitRowB;
     if (trans) has_mask ? go(k_gemm_nt<MT, WC, true, true, true, true>, lds) : go(k_gemm_nt<MT, WC, true, true, true, false>, lds);
     else has_mask ? go(k_gemm_nt<MT, WC, true, false, true, true>, lds) : go(k_gemm_nt<MT, WC, true, false, true, false>, lds);
