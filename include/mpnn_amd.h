@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 3
+#define MPNN_ABI_VERSION 4
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -295,7 +295,7 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
                           mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
- * Dense fp32 GEMMs of the layer on the matrix cores (exact f32 MFMA).
+ * Dense fp32 GEMMs of the layer on the matrix cores.
  *
  * Replace the node-level Linear calls of the reference and their autograd backward:
  *   models/layers.py:104 fused_linear(x); models/layers.py:56 linear(...) after the column split;
@@ -307,8 +307,14 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
  *   same entry point computes input gradients (dX = G W  ==  G (W^T)^T).
  *   Y2 (optional, with emul [N,M]): second output Y2 = Y * emul written by the same epilogue
  *   (d aggr and d A = d aggr * cnt leave one GEMM together).
+ *   Arithmetic: by default every float32 operand is split into three bfloat16 pieces and the products run on
+ *   the bfloat16 matrix cores with float32 accumulation (six piece products per product; error against a
+ *   float64 product no larger than the float32 matrix cores'); MPNN_GEMM=f32 in the environment selects the
+ *   float32 matrix-core instructions, which unaligned operands (K % 4 != 0) always take.
  * mpnn_gemm_tn_f32:  dW[M,K] = (G * (mask > 0))[N,M]^T X[N,K]  (weight gradient; rows are summed in a fixed
  *   order through `scratch`, float, at least mpnn_gemm_tn_scratch_floats(N, M, K) elements).
+ *   Gout (optional, [N,M], needs 16-byte aligned operands): G * (mask > 0) is also written out, so that the
+ *   other GEMMs of the backward read one matrix instead of two.  Runs on the float32 matrix-core instructions.
  * All matrices row-major with leading dimensions in elements.
  * ------------------------------------------------------------------------- */
 int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int64_t ldm1,
@@ -319,7 +325,7 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K);
 int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm,
                          const float* X, int64_t ldx, float* dW, int64_t lddw, float* scratch,
-                         int64_t N, int32_t M, int32_t K, mpnn_stream_t stream);
+                         float* Gout, int64_t ldgo, int64_t N, int32_t M, int32_t K, mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Segment mean over an index list: out[g, :] = (1/max(cnt_g,1)) * sum_{p in seg g} x[col[p], :]

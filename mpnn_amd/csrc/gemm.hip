@@ -455,6 +455,7 @@ struct TnArgs {
   const float* G; int64_t ldg;        // [N, M]
   const float* mask; int64_t ldm;     // optional [N, M]: G is used where mask > 0
   const float* X; int64_t ldx;        // [N, K]
+  float* gout; int64_t ldgo;          // optional [N, M]: G * (mask > 0), written by the blocks of the first K tile
   float* partial;                     // [gridDim.x][M][K]
   int64_t N; int M; int K;
 };
@@ -497,12 +498,18 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
       xv[q] = valid4(k0 + c4, a.K, row_ok);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, int64_t nslab) {
+    const bool emit = ALIGNED && a.gout && blockIdx.z == 0;   // uniform
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int idx = tid + kBlock * q;
       float4 g = select4(gr[q], gv[q]);
       if (a.mask) g = relu_mask4(g, mr[q]);
+      if (emit) {   // the masked gradient, one whole 512-byte row per 32 lanes
+        const int64_t row = nslab + (idx >> 5);
+        const int col = m0 + (idx & 31) * 4;
+        if (row < a.N && col < a.M) *reinterpret_cast<float4*>(a.gout + row * a.ldgo + col) = g;
+      }
       *reinterpret_cast<float4*>(&Gs[buf][idx >> 5][(idx & 31) * 4]) = g;
       *reinterpret_cast<float4*>(&Xs[buf][idx >> 5][(idx & 31) * 4]) = select4(xr[q], xv[q]);
     }
@@ -513,7 +520,7 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
   int buf = 0;
   if (n0 < a.N) {
     fetch(n0);
-    stash(0);
+    stash(0, n0);
   }
   __syncthreads();
   for (; n0 < a.N; n0 += step, buf ^= 1) {
@@ -529,7 +536,7 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
-    if (more) stash(buf ^ 1);
+    if (more) stash(buf ^ 1, n0 + step);
     __syncthreads();
   }
   float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
@@ -618,9 +625,12 @@ static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
   if (trans) {
     if (aligned) go(k_gemm_nt<MT, WC, true, true, false, true>, lds);
     else go(k_gemm_nt<MT, WC, false, true, false, true>, lds);
-  } else {
+  } else if (has_mask) {
     if (aligned) go(k_gemm_nt<MT, WC, true, false, false, true>, lds);
     else go(k_gemm_nt<MT, WC, false, false, false, true>, lds);
+  } else {
+    if (aligned) go(k_gemm_nt<MT, WC, true, false, false, false>, lds);
+    else go(k_gemm_nt<MT, WC, false, false, false, false>, lds);
   }
 }
 
@@ -662,8 +672,8 @@ int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K) {
 }
 
 int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm, const float* X, int64_t ldx,
-                         float* dW, int64_t lddw, float* scratch, int64_t N, int32_t M, int32_t K,
-                         mpnn_stream_t stream) {
+                         float* dW, int64_t lddw, float* scratch, float* Gout, int64_t ldgo, int64_t N, int32_t M,
+                         int32_t K, mpnn_stream_t stream) {
   if (N < 0 || M < 1 || K < 1) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: bad sizes");
   if (!dW) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: dW is null");
   if (lddw < K) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: lddw below K");
@@ -673,10 +683,12 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
   }
   if (!G || !X || !scratch) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: null pointer argument");
   if (ldg < M || ldx < K || (mask && ldm < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: leading dimension too small");
-  TnArgs a{G, ldg, mask, ldm, X, ldx, scratch, N, M, K};
+  TnArgs a{G, ldg, mask, ldm, X, ldx, Gout, ldgo, scratch, N, M, K};
   const int slabs = tn_slabs(N, M, K);
   const bool aligned = !(((uintptr_t)G & 15) || ((uintptr_t)X & 15) || (ldg & 3) || (ldx & 3) || (M & 3) || (K & 3) ||
                          (mask && (((uintptr_t)mask & 15) || (ldm & 3))));
+  if (Gout && (!aligned || ldgo < M || ((uintptr_t)Gout & 15) || (ldgo & 3)))
+    return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: Gout needs 16-byte aligned operands and ldgo >= M");
   dim3 grid(slabs, (M + 127) / 128, (K + 127) / 128);
   if (aligned) k_gemm_tn<true><<<grid, kBlock, 0, stream>>>(a);
   else k_gemm_tn<false><<<grid, kBlock, 0, stream>>>(a);

@@ -55,8 +55,9 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=N
     return y
 
 
-def gemm_tn(g, x, mask=None, out=None) -> torch.Tensor:
-    """(g * (mask > 0))^T @ x  ->  [M, K]; ``out`` may be a column slice of a wider weight gradient."""
+def gemm_tn(g, x, mask=None, out=None, g_out=None) -> torch.Tensor:
+    """(g * (mask > 0))^T @ x  ->  [M, K]; ``out`` may be a column slice of a wider weight gradient.
+    ``g_out`` ([N, M]) receives g * (mask > 0)."""
     lib = _lib.load()
     g, x = _rows(g), _rows(x)
     n, m = g.shape
@@ -67,7 +68,8 @@ def gemm_tn(g, x, mask=None, out=None) -> torch.Tensor:
     scratch = _scratch(lib.mpnn_gemm_tn_scratch_floats(n, m, k), g.device)
     _lib.check(lib.mpnn_gemm_tn_f32(
         _lib.ptr(g), g.stride(0), _lib.ptr(mask), mask.stride(0) if mask is not None else 0, _lib.ptr(x),
-        x.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(scratch), n, m, k, _lib.stream_handle(g.device)),
+        x.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(scratch), _lib.ptr(g_out),
+        g_out.stride(0) if g_out is not None else 0, n, m, k, _lib.stream_handle(g.device)),
         "mpnn_gemm_tn_f32")
     return out
 

@@ -49,17 +49,24 @@ class _LayerFn(torch.autograd.Function):
         gy = gy if gy.is_contiguous() else gy.contiguous()
         wt_out = w_out.t().contiguous()               # [F+H, H]
         g_ab = torch.empty_like(ab)
-        ga = gemm_nt(gy, wt_out[f:], mask1=y, emul=cnt, out2=g_ab[:, :h])
+        g_wout = torch.empty_like(w_out) if ctx.needs_input_grad[4] else None
+        g, m = gy, y
+        # gz = gy * [y > 0] leaves the first weight-gradient GEMM as a by-product (written in whole 512-byte rows),
+        # so the four GEMMs after it read one matrix instead of (gy, y); needs 16-byte aligned rows
+        if g_wout is not None and h % 4 == 0 and f % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, y, x)):
+            gz = torch.empty_like(gy)
+            gemm_tn(gy, x, mask=y, out=g_wout[:, :f], g_out=gz)
+            g, m = gz, None
+        elif g_wout is not None:
+            gemm_tn(gy, x, mask=y, out=g_wout[:, :f])
+        ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt, out2=g_ab[:, :h])
         g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = gemm_nt(gy, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=y)
+            gx = gemm_nt(g, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=m)
         g_wn = gemm_tn(g_ab, x) if ctx.needs_input_grad[2] else None
-        g_wout = None
-        if ctx.needs_input_grad[4]:
-            g_wout = torch.empty_like(w_out)
-            gemm_tn(gy, x, mask=y, out=g_wout[:, :f])
-            gemm_tn(gy, aggr, mask=y, out=g_wout[:, f:])
+        if g_wout is not None:
+            gemm_tn(g, aggr, mask=m, out=g_wout[:, f:])
         return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
 
 
