@@ -155,6 +155,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture one step (forward+backward) into a HIP graph and time replays (single GPU)")
+    ap.add_argument("--first-layer", action="store_true",
+                    help="time the layer as the FIRST layer of a model: x is data, no gradient with respect to x "
+                         "(default: a middle layer, every gradient including the input's)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -193,7 +196,7 @@ def main():
     layer = (MPNNLayerSum if args.mode == "sum" else MPNNLayerCat)(F_in, Fe, H).to(dev, dtype)
 
     if world == 1:
-        x = d["x"].to(dtype).requires_grad_(True)
+        x = d["x"].to(dtype).requires_grad_(not args.first_layer)
         ei, ea = d["edge_index"], d["edge_attr"].to(dtype)
         from mpnn_amd.graph import MPGraph, graph_for
         graph_for(ei, n_total)            # built once and cached, outside the timed region (static graph)
@@ -211,7 +214,7 @@ def main():
     else:
         graph_build_ms = None
         pg = PartitionedGraph(d["edge_index"], n_total, rank, world)
-        x = pg.local_rows(d["x"]).to(dtype).clone().requires_grad_(True)
+        x = pg.local_rows(d["x"]).to(dtype).clone().requires_grad_(not args.first_layer)
         ea = pg.local_edges(d["edge_attr"]).to(dtype).clone()
         n_rows_fwd, n_rows_bwd, e_local = pg.n_local, world * pg.n_pad, pg.edge_ids.numel()
         forward = lambda: partitioned_layer(layer, x, pg, ea)
@@ -303,7 +306,8 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['desc']}" + (f" (scale {args.scale})" if args.scale != 1 else ""),
-                       "layer": f"MPNNLayer{args.mode.capitalize()}", "num_nodes": n_total, "num_edges": e_total,
+                       "layer": f"MPNNLayer{args.mode.capitalize()}" + (" (first layer: no input gradient)" if args.first_layer else ""),
+                       "num_nodes": n_total, "num_edges": e_total,
                        "in_features": F_in, "hidden": H, "edge_features": Fe,
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world} + halo all-gather",
                        "launch": "HIP graph replay" if run_step is not step else "eager"},

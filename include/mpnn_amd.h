@@ -327,6 +327,15 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
                          const float* X, int64_t ldx, float* dW, int64_t lddw, float* scratch,
                          float* Gout, int64_t ldgo, int64_t N, int32_t M, int32_t K, mpnn_stream_t stream);
 
+/* bfloat16 form of mpnn_gemm_nt_f32 for bfloat16 models (bf16 storage, float32 accumulation, no operand mask):
+ *   Y[N,M] = act( X1 W1^T + X2 W2^T ),  optionally  Y2 = Y * emul  with emul float32 [N,M].
+ * M, K1, K2 multiples of 8; X, W, emul 16-byte aligned, Y and Y2 8-byte aligned, with row strides that keep
+ * every row so. */
+int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W1, int64_t ldw1, int32_t K1,
+                          const void* X2, int64_t ldx2, const void* W2, int64_t ldw2, int32_t K2, void* Y,
+                          int64_t ldy, const float* emul, int64_t ldemul, void* Y2, int64_t ldy2, int64_t N,
+                          int32_t M, int32_t relu, mpnn_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * Segment mean over an index list: out[g, :] = (1/max(cnt_g,1)) * sum_{p in seg g} x[col[p], :]
  * and its backward gx[col[p], :] = gout[g, :] / max(cnt_g, 1).

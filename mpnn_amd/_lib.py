@@ -85,6 +85,9 @@ SIGNATURES = {
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32,
                                    c_int32, c_void_p]),
+    "mpnn_gemm_nt_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p,
+                                    c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_gemm_tn_scratch_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "mpnn_gemm_tn_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),

@@ -1,0 +1,252 @@
+// Tall-skinny bfloat16 GEMM of the MPNN layer for bfloat16 models (bf16 storage, float32 accumulation on
+// v_mfma_f32_32x32x16_bf16):
+//
+//   Y[N,M] = relu?( X1[N,K1] W1[M,K1]^T + X2[N,K2] W2[M,K2]^T ),   optionally  Y2 = Y * emul  (emul float32)
+//
+// the node-level Linear calls of the reference (models/layers.py:56,69,104,140) and, with pre-transposed
+// weights, the input-gradient products of their backward.  Same block geometry as the float32 kernel
+// (128-row steps, 4 x WC waves, wave = 32 rows x 32 MT columns), 64-wide k-chunks double-buffered in LDS, loads
+// one chunk ahead in registers, issued unconditionally with a scalar base and a 32-bit lane offset.
+// The MFMA operand roles are swapped (accumulator = transposed output tile) so that a lane ends up with 4
+// consecutive output columns per register quad and stores them as one 8-byte word.
+// Requirements (checked on the host): K1, K2, M multiples of 8; rows 16-byte aligned.
+#include <type_traits>
+
+#include "common.h"
+#include "rowio.h"
+
+namespace mpnn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kBfBK = 64;                  // k-chunk (elements)
+constexpr int kBfRowB = kBfBK * 2 + 16;    // LDS row: 144 bytes = 9 sixteen-byte slots (odd => conflict-free b128)
+constexpr int kBfBN = 128;                 // rows of X per block step
+
+struct NtBf16Seg {
+  const bf16_t* X; int64_t ldx;   // [N, K]
+  const bf16_t* W; int64_t ldw;   // [M, K]
+  int K;
+};
+
+struct NtBf16Args {
+  NtBf16Seg seg[2];
+  int nseg;
+  bf16_t* Y; int64_t ldy;
+  const float* emul; int64_t ldemul;   // optional [N, M] float32: second output Y2 = Y * emul
+  bf16_t* Y2; int64_t ldy2;
+  int64_t N; int M;
+  int relu;
+};
+
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+  const f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // round to nearest even
+}
+
+template <int MT, int WC>
+__global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt_bf16(NtBf16Args a) {
+  constexpr int NTHREADS = kBlock * WC;
+  constexpr int WROWS = 32 * MT * WC;
+  constexpr int QPR = kBfBK / 8;                                      // 16-byte loads per row and chunk
+  constexpr int XQ = (kBfBN * QPR) / NTHREADS;
+  constexpr int WQ = (WROWS * QPR + NTHREADS - 1) / NTHREADS;
+  constexpr int STAGEB = (kBfBN + WROWS) * kBfRowB;
+  extern __shared__ float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int wr = wid & 3, wc = wid >> 2;
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * WROWS;
+  const int nch0 = (a.seg[0].K + kBfBK - 1) / kBfBK;
+  const int nch = nch0 + (a.nseg > 1 ? (a.seg[1].K + kBfBK - 1) / kBfBK : 0);
+  const int64_t nsteps_all = (a.N + kBfBN - 1) / kBfBN;
+  const int64_t my_steps = blockIdx.x < nsteps_all ? (nsteps_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t total = my_steps * nch;
+  if (total == 0) return;   // uniform over the block
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int c = 0; c < MT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  uint4 xr[2][XQ], wreg[2][WQ];
+  int ck[2], cK[2];                              // k origin and row length of the chunk a set holds
+  int64_t f_row0 = (int64_t)blockIdx.x * kBfBN;  // position of the next fetch in the (row step, chunk) sequence
+  int f_c = 0;
+
+  auto fetch = [&](auto S) {
+    constexpr int st = decltype(S)::value;
+    const int c = f_c;
+    const int64_t row0 = f_row0;
+    if (++f_c == nch) { f_c = 0; f_row0 += (int64_t)gridDim.x * kBfBN; }
+    const NtBf16Seg& sg = a.seg[c < nch0 ? 0 : 1];
+    const int k0 = (c < nch0 ? c : c - nch0) * kBfBK;
+    ck[st] = k0;
+    cK[st] = sg.K;
+    const int64_t left = a.N - 1 - row0;
+    const int rt_max = left < kBfBN - 1 ? (left < 0 ? 0 : (int)left) : kBfBN - 1;
+    const int64_t rbase = row0 <= a.N - 1 ? row0 : a.N - 1;
+    const bf16_t* xb = sg.X + rbase * sg.ldx;
+    const bf16_t* wb = sg.W + (int64_t)m0 * sg.ldw;
+    const int r_max = a.M - 1 - m0 < WROWS - 1 ? a.M - 1 - m0 : WROWS - 1;
+    const uint32_t ldx = (uint32_t)sg.ldx, ldw = (uint32_t)sg.ldw;
+    const bool tail = k0 + kBfBK > sg.K;
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {   // weights first (L2): waiting for them leaves the X loads in flight
+      const int idx = tid + NTHREADS * q;
+      int kk = k0 + (idx % QPR) * 8;
+      if (tail) kk = kk < sg.K ? kk : sg.K - 8;
+      int r = idx / QPR;
+      r = r < r_max ? r : r_max;
+      wreg[st][q] = *reinterpret_cast<const uint4*>(wb + ((uint32_t)r * ldw + (uint32_t)kk));
+    }
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      int kk = k0 + (idx % QPR) * 8;
+      if (tail) kk = kk < sg.K ? kk : sg.K - 8;
+      int rt = idx / QPR;
+      rt = rt < rt_max ? rt : rt_max;
+      xr[st][q] = *reinterpret_cast<const uint4*>(xb + ((uint32_t)rt * ldx + (uint32_t)kk));
+    }
+  };
+  auto stash = [&](auto S, int buf) {
+    constexpr int st = decltype(S)::value;
+    char* Xs = ldsb + buf * STAGEB;
+    char* Ws = Xs + kBfBN * kBfRowB;
+    const bool tail = ck[st] + kBfBK > cK[st];   // uniform: columns past the row's end must multiply as zeros
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      uint4 v = xr[st][q];
+      if (tail && ck[st] + (idx % QPR) * 8 >= cK[st]) v = zero;
+      *reinterpret_cast<uint4*>(Xs + (idx / QPR) * kBfRowB + (idx % QPR) * 16) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < WQ; ++q) {
+      const int idx = tid + NTHREADS * q;
+      uint4 v = wreg[st][q];
+      if (tail && ck[st] + (idx % QPR) * 8 >= cK[st]) v = zero;
+      if (idx / QPR < WROWS) *reinterpret_cast<uint4*>(Ws + (idx / QPR) * kBfRowB + (idx % QPR) * 16) = v;
+    }
+  };
+
+  int64_t step = 0;
+  int c = 0;
+  auto body = [&](auto S, int64_t it) {
+    constexpr int st = decltype(S)::value;   // == it & 1: LDS buffer and the register set chunk it + 2 goes to
+    using Next = std::integral_constant<int, st ^ 1>;
+    const int64_t row0 = (blockIdx.x + step * gridDim.x) * kBfBN;
+    const bool last_chunk = c + 1 == nch;
+    fetch(S);   // chunk it + 2 into the set chunk it left when it was stashed (unconditional, see header)
+    const char* Xs = ldsb + st * STAGEB;
+    const char* Ws = Xs + kBfBN * kBfRowB;
+    const char* xrow = Xs + (wr * 32 + li) * kBfRowB + lh * 16;
+#pragma unroll
+    for (int s = 0; s < kBfBK / 16; ++s) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(xrow + s * 32);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(Ws + ((wc * MT + t) * 32 + li) * kBfRowB + lh * 16 + s * 32);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[t], 0, 0, 0);
+      }
+    }
+    if (last_chunk) {
+      // transposed tile: output row = lane & 31, column within the 32-wide tile = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+      const int64_t row = row0 + wr * 32 + li;
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int col = m0 + (wc * MT + t) * 32 + 8 * i + 4 * lh;
+          float4 v = make_float4(acc[t][4 * i], acc[t][4 * i + 1], acc[t][4 * i + 2], acc[t][4 * i + 3]);
+          if (a.relu) {
+            v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
+            v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
+          }
+          if (row < a.N && col < a.M) {
+            *reinterpret_cast<uint2*>(a.Y + row * a.ldy + col) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+            if (a.Y2) {
+              const float4 e = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
+              *reinterpret_cast<uint2*>(a.Y2 + row * a.ldy2 + col) =
+                  make_uint2(pack2_bf16(v.x * e.x, v.y * e.y), pack2_bf16(v.z * e.z, v.w * e.w));
+            }
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      }
+      ++step;
+      c = 0;
+    } else {
+      ++c;
+    }
+    if (it + 1 < total) stash(Next{}, st ^ 1);
+    __syncthreads();
+  };
+
+  // prologue: chunk 0 in LDS, chunk 1 in flight in set 1 (set 0 is refilled with chunk 2 by the first body)
+  fetch(std::integral_constant<int, 0>{});
+  fetch(std::integral_constant<int, 1>{});
+  stash(std::integral_constant<int, 0>{}, 0);
+  __syncthreads();
+  for (int64_t it = 0; it < total; it += 2) {
+    body(std::integral_constant<int, 0>{}, it);
+    if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
+  }
+}
+
+template <int MT, int WC>
+static void launch_nt_bf16(const NtBf16Args& a, hipStream_t stream) {
+  int64_t blocks = (a.N + kBfBN - 1) / kBfBN;
+  if (blocks > 1024) blocks = 1024;
+  constexpr int WROWS = 32 * MT * WC;
+  dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
+  const size_t lds = (size_t)2 * (kBfBN + WROWS) * kBfRowB;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<MT, WC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  k_gemm_nt_bf16<MT, WC><<<grid, kBlock * WC, lds, stream>>>(a);
+}
+
+}  // namespace mpnn
+
+using namespace mpnn;
+
+extern "C" int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W1, int64_t ldw1, int32_t K1,
+                                     const void* X2, int64_t ldx2, const void* W2, int64_t ldw2, int32_t K2, void* Y,
+                                     int64_t ldy, const float* emul, int64_t ldemul, void* Y2, int64_t ldy2,
+                                     int64_t N, int32_t M, int32_t relu, mpnn_stream_t stream) {
+  if (N < 0 || M < 8 || K1 < 8 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: bad sizes");
+  if ((M | K1 | K2) & 7) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: M, K1 and K2 must be multiples of 8");
+  if (N == 0) return MPNN_OK;
+  if (!X1 || !W1 || !Y || (K2 > 0 && (!X2 || !W2))) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: null pointer argument");
+  if (ldx1 < K1 || ldw1 < K1 || ldy < M || (K2 > 0 && (ldx2 < K2 || ldw2 < K2)))
+    return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: leading dimension too small");
+  if (Y2 && (!emul || ldemul < M || ldy2 < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: Y2 needs emul and ld >= M");
+  const uintptr_t ptrs = (uintptr_t)X1 | (uintptr_t)W1 | (uintptr_t)X2 | (uintptr_t)W2 | (uintptr_t)emul;
+  if ((ptrs & 15) || (((uintptr_t)Y | (uintptr_t)Y2) & 7) || ((ldx1 | ldw1 | ldx2 | ldw2) & 7) || ((ldy | ldy2 | ldemul) & 3))
+    return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: operands must be 16-byte aligned with row strides that keep them so");
+  NtBf16Args a;
+  a.seg[0] = NtBf16Seg{static_cast<const bf16_t*>(X1), ldx1, static_cast<const bf16_t*>(W1), ldw1, K1};
+  a.seg[1] = NtBf16Seg{static_cast<const bf16_t*>(X2), ldx2, static_cast<const bf16_t*>(W2), ldw2, K2};
+  a.nseg = K2 > 0 ? 2 : 1;
+  a.Y = static_cast<bf16_t*>(Y); a.ldy = ldy;
+  a.emul = emul; a.ldemul = ldemul;
+  a.Y2 = static_cast<bf16_t*>(Y2); a.ldy2 = ldy2;
+  a.N = N; a.M = M; a.relu = relu;
+  if (M <= 32) launch_nt_bf16<1, 1>(a, stream);
+  else if (M <= 64) launch_nt_bf16<2, 1>(a, stream);
+  else if (M <= 128) launch_nt_bf16<4, 1>(a, stream);
+  else launch_nt_bf16<4, 2>(a, stream);
+  MPNN_LAUNCH_CHECK("k_gemm_nt_bf16");
+  return MPNN_OK;
+}

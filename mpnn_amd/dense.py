@@ -55,6 +55,36 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=N
     return y
 
 
+def bf16_ok(*ts) -> bool:
+    """True if every matrix can go through mpnn_gemm_nt_bf16: bfloat16, unit column stride, a width that is a
+    multiple of 8 and 16-byte aligned rows."""
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.bfloat16 and t.dim() == 2 and t.stride(1) == 1):
+            return False
+        if t.size(1) % 8 or t.stride(0) % 8 or t.data_ptr() % 16:
+            return False
+    return True
+
+
+def gemm_nt_bf16(x1, w1, x2=None, w2=None, relu=False, emul=None, out2=None) -> torch.Tensor:
+    """bfloat16 act(x1 @ w1^T [+ x2 @ w2^T]) with float32 accumulation; ``emul`` (float32 [N, M]) and ``out2``
+    (bfloat16 [N, M] view) give the second output out2 = result * emul."""
+    lib = _lib.load()
+    n, k1 = x1.shape
+    m = w1.size(0)
+    y = torch.empty((n, m), dtype=torch.bfloat16, device=x1.device)
+    _lib.check(lib.mpnn_gemm_nt_bf16(
+        _lib.ptr(x1), x1.stride(0), _lib.ptr(w1), w1.stride(0), k1,
+        _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(w2), w2.stride(0) if w2 is not None else 0,
+        x2.size(1) if x2 is not None else 0,
+        _lib.ptr(y), y.stride(0), _lib.ptr(emul), emul.stride(0) if emul is not None else 0, _lib.ptr(out2),
+        out2.stride(0) if out2 is not None else 0, n, m, 1 if relu else 0, _lib.stream_handle(x1.device)),
+        "mpnn_gemm_nt_bf16")
+    return y
+
+
 def gemm_tn(g, x, mask=None, out=None, g_out=None) -> torch.Tensor:
     """(g * (mask > 0))^T @ x  ->  [M, K]; ``out`` may be a column slice of a wider weight gradient.
     ``g_out`` ([N, M]) receives g * (mask > 0)."""

@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .dense import gemm_nt, gemm_tn
+from .dense import gemm_nt, gemm_nt_bf16, gemm_tn
 from .graph import MPGraph
 
 
@@ -70,10 +70,64 @@ class _LayerFn(torch.autograd.Function):
         return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
 
 
+class _LayerFnBf16(torch.autograd.Function):
+    """The same node for bfloat16 models: bf16 storage, float32 accumulation.  The products with a huge row count
+    run on mpnn_gemm_nt_bf16; the three small weight-gradient products (reductions over the rows) go to the
+    library GEMM of torch; the relu backward is one elementwise pass."""
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
+        f = x.size(1)
+        h = w_out.size(0)
+        ab = gemm_nt_bf16(x, w_nodes.contiguous())
+        a, b = ab[:, :h], ab[:, h:]
+        ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
+        w_edge_c = w_edge.contiguous()
+        want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
+        aggr, cnt, maskbits = ops._run_forward(a, b, ea_s, w_edge_c, graph.by_dst, graph, want)
+        wt = w_out.t().contiguous()                   # [F+H, H]; its transpose halves are needed both ways
+        y = gemm_nt_bf16(x, w_out[:, :f].contiguous(), aggr, w_out[:, f:].contiguous(), relu=True)
+        if want:
+            if maskbits is not None:
+                graph.tpos
+            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge_c, wt)
+            ctx.graph = graph
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, wt = ctx.saved_tensors
+        graph = ctx.graph
+        f = x.size(1)
+        h = wt.size(1)
+        gz = torch.ops.aten.threshold_backward(gy.contiguous(), y, 0)      # gy * [y > 0]
+        g_ab = torch.empty_like(ab)
+        ga = gemm_nt_bf16(gz, wt[f:], emul=cnt, out2=g_ab[:, :h])
+        g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_nt_bf16(gz, wt[:f], g_ab, w_nodes.t().contiguous())
+        g_wn = g_ab.t().mm(x) if ctx.needs_input_grad[2] else None
+        g_wout = None
+        if ctx.needs_input_grad[4]:
+            g_wout = torch.cat([gz.t().mm(x), gz.t().mm(aggr)], dim=1)
+        return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
+
+
 def supported(x, edge_attr, *weights) -> bool:
-    return x.is_cuda and all(t.dtype == torch.float32 for t in (x, edge_attr) + weights)
+    if not x.is_cuda:
+        return False
+    ts = (x, edge_attr) + weights
+    if all(t.dtype == torch.float32 for t in ts):
+        return True
+    # bfloat16: every width a multiple of 8 (16-byte rows); weights are checked by their shapes
+    if all(t.dtype == torch.bfloat16 for t in ts):
+        h = weights[-1].size(0)
+        return x.dim() == 2 and x.size(1) % 8 == 0 and h % 8 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0
+    return False
 
 
 @torch.compiler.disable
 def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph) -> torch.Tensor:
-    return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)
+    fn = _LayerFnBf16 if x.dtype == torch.bfloat16 else _LayerFn
+    return fn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)

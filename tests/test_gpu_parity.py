@@ -398,3 +398,41 @@ def test_split_bf16_gemm_is_as_accurate_as_the_float32_matrix_cores(n, k1, k2, m
         err[mode] = float((y - ref).abs().max() / ref.abs().max())
     assert err["f32"] < 2e-6 and err["split"] < 2e-6, err
     assert err["split"] <= 2.0 * err["f32"] + 1e-7, err
+
+
+# --------------------------------------------------------------------------- bfloat16 layer node
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sum", "cat"])
+@pytest.mark.parametrize("n,e,f,h,fe", [(400, 5000, 16, 64, 4), (300, 9000, 128, 128, 4), (200, 1500, 8, 8, 1)])
+def test_bf16_layer_node_against_the_oracle(mode, n, e, f, h, fe):
+    """bfloat16 models whose widths are multiples of 8 run the layer as one node on mpnn_gemm_nt_bf16 + the edge
+    kernels; against the float32 oracle on the same (bf16-rounded) inputs the bar is the bfloat16 one."""
+    from mpnn_amd import MPNNLayerCat, MPNNLayerSum, layer_fn
+    gen = torch.Generator().manual_seed(n + h)
+    dst = (torch.rand(e, generator=gen) ** 3 * n).long().clamp_(max=n - 1)     # skewed: some split rows
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), dst])
+    rnd = lambda *s: torch.randn(*s, generator=gen).bfloat16().float()
+    x, ea, r = rnd(n, f), torch.rand(e, fe, generator=gen).bfloat16().float(), rnd(n, h)
+    torch.manual_seed(7)
+    layer = (MPNNLayerSum if mode == "sum" else MPNNLayerCat)(f, fe, h)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(p.bfloat16().float())
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xc = x.clone().requires_grad_(True)
+    if mode == "sum":
+        want = O.layer_sum(xc, ei, ea, params["fused_linear.weight"], params["linear_3.weight"], params["linear_out.weight"])
+    else:
+        want = O.layer_cat(xc, ei, ea, params["linear.weight"], params["linear_out.weight"])
+    (want * r).sum().backward()
+
+    layer = layer.cuda().bfloat16()
+    xg = x.cuda().bfloat16().requires_grad_(True)
+    assert layer_fn.supported(xg, ea.cuda().bfloat16(), *[p for p in layer.parameters()])
+    got = layer(xg, ei.cuda(), ea.cuda().bfloat16())
+    assert got.dtype == torch.bfloat16
+    (got.float() * r.cuda()).sum().backward()
+    assert_close(got.float(), want, RTOL16, what="out")
+    assert_close(xg.grad.float(), xc.grad, RTOL16, atol_scale=2.0, what="grad x")
+    for k, p in layer.named_parameters():
+        assert_close(p.grad.float(), params[k].grad, RTOL16, atol_scale=2.0, what=f"grad {k}")
