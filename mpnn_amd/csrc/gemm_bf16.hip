@@ -217,6 +217,180 @@ static void launch_nt_bf16(const NtBf16Args& a, hipStream_t stream) {
   k_gemm_nt_bf16<MT, WC><<<grid, kBlock * WC, lds, stream>>>(a);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight-gradient product for bfloat16 models (the reductions over the rows in the backward of the Linear
+// calls at models/layers.py:56,69,104,140):
+//
+//   dW[M,K] = (G * [mask > 0])^T X        G, mask [N,M], X [N,K] bfloat16; float32 accumulation
+//
+// The contraction runs over the rows, which are the slow index of both operands, while a lane of
+// v_mfma_f32_32x32x16_bf16 wants 8 contraction values of one output row.  Slabs of 32 rows go to LDS as they
+// lie in memory (16-byte stores) and every lane collects its 8 values with 16-bit LDS reads.  The order of the
+// contraction values inside one instruction is free as long as both operands use the same one: lane half h,
+// value j stands for row 2 j + h of the 16-row step, so the two halves read adjacent LDS rows, which the
+// 320-byte row pitch (80 dwords = 16 mod 32) puts on disjoint banks.
+constexpr int kTnRows = 32;
+constexpr int kTnRowB = 128 * 2 + 64;
+
+struct TnBf16Args {
+  const bf16_t* G; int64_t ldg;      // [N, M]
+  const bf16_t* mask; int64_t ldm;   // optional [N, M]
+  const bf16_t* X; int64_t ldx;      // [N, K]
+  bf16_t* gout; int64_t ldgo;        // optional [N, M]: G * [mask > 0], written by the blocks of the first K tile
+  float* partial;                    // [gridDim.x][M][K]
+  int64_t N; int M; int K;
+};
+
+// Two packed bfloat16 of g where the matching entries of y are > 0 (NaN counts as > 0, like `y <= 0 ? 0 : g`).
+__device__ __forceinline__ uint32_t relu_mask2(uint32_t g, uint32_t y) {
+  const uint32_t lo = y & 0xffffu, hi = y >> 16;
+  const bool keep_lo = (lo & 0x7fffu) != 0u && (!(lo & 0x8000u) || (lo & 0x7fffu) > 0x7f80u);
+  const bool keep_hi = (hi & 0x7fffu) != 0u && (!(hi & 0x8000u) || (hi & 0x7fffu) > 0x7f80u);
+  return g & ((keep_lo ? 0xffffu : 0u) | (keep_hi ? 0xffff0000u : 0u));
+}
+
+// 8 contraction values of one output column: 16-bit LDS reads two rows apart, packed in pairs.
+__device__ __forceinline__ bf16x8 read_col8(const char* p) {
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t lo = *reinterpret_cast<const uint16_t*>(p + (4 * q) * kTnRowB);
+    const uint32_t hi = *reinterpret_cast<const uint16_t*>(p + (4 * q + 2) * kTnRowB);
+    w[q] = lo | (hi << 16);
+  }
+  return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+}
+
+// Output tile 128 (m) x 128 (k) per block; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles); blockIdx.x
+// walks the row slabs with stride gridDim.x and leaves one partial tile.
+template <bool MASKED>
+__global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
+  __shared__ __attribute__((aligned(16))) char Gs[2][kTnRows * kTnRowB];
+  __shared__ __attribute__((aligned(16))) char Xs[2][kTnRows * kTnRowB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
+  const int m0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // a thread moves two 16-byte pieces per matrix and slab: rows tid/16 and tid/16 + 16, columns 8 (tid % 16) ..
+  const int pr = tid >> 4, pc = (tid & 15) * 8;
+  const bool g_ok = m0 + pc < a.M, x_ok = k0 + pc < a.K;   // widths are multiples of 8: a piece is in or out
+  const int gcol = g_ok ? m0 + pc : 0, xcol = x_ok ? k0 + pc : 0;
+  uint4 gr[2], mr[2], xr[2];
+  bool rv[2];
+  auto fetch = [&](int64_t n0) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int64_t row = n0 + pr + 16 * q;
+      rv[q] = row < a.N;   // rows past the end must contribute exact zeros to the sums
+      row = rv[q] ? row : a.N - 1;
+      gr[q] = *reinterpret_cast<const uint4*>(a.G + row * a.ldg + gcol);
+      if constexpr (MASKED) mr[q] = *reinterpret_cast<const uint4*>(a.mask + row * a.ldm + gcol);
+      xr[q] = *reinterpret_cast<const uint4*>(a.X + row * a.ldx + xcol);
+    }
+  };
+  auto stash = [&](int buf, int64_t nslab) {
+    const bool emit = a.gout && blockIdx.z == 0;   // uniform
+    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      uint4 g = (rv[q] && g_ok) ? gr[q] : zero;
+      if constexpr (MASKED) {
+        g.x = relu_mask2(g.x, mr[q].x); g.y = relu_mask2(g.y, mr[q].y);
+        g.z = relu_mask2(g.z, mr[q].z); g.w = relu_mask2(g.w, mr[q].w);
+      }
+      const int r = pr + 16 * q;
+      if (emit && rv[q] && g_ok)   // the masked gradient, one whole 256-byte row per 16 lanes
+        *reinterpret_cast<uint4*>(a.gout + (nslab + r) * a.ldgo + gcol) = g;
+      *reinterpret_cast<uint4*>(&Gs[buf][r * kTnRowB + pc * 2]) = g;
+      *reinterpret_cast<uint4*>(&Xs[buf][r * kTnRowB + pc * 2]) = (rv[q] && x_ok) ? xr[q] : zero;
+    }
+  };
+
+  const int64_t step = (int64_t)gridDim.x * kTnRows;
+  int64_t n0 = (int64_t)blockIdx.x * kTnRows;
+  int buf = 0;
+  if (n0 < a.N) {
+    fetch(n0);
+    stash(0, n0);
+  }
+  __syncthreads();
+  for (; n0 < a.N; n0 += step, buf ^= 1) {
+    const bool more = n0 + step < a.N;
+    if (more) fetch(n0 + step);
+    const char* gp = &Gs[buf][lh * kTnRowB + (wm + li) * 2];
+    const char* xp = &Xs[buf][lh * kTnRowB + (wk + li) * 2];
+#pragma unroll
+    for (int s = 0; s < kTnRows / 16; ++s) {
+      const bf16x8 a0 = read_col8(gp + s * 16 * kTnRowB), a1 = read_col8(gp + s * 16 * kTnRowB + 64);
+      const bf16x8 b0 = read_col8(xp + s * 16 * kTnRowB), b1 = read_col8(xp + s * 16 * kTnRowB + 64);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1, n0 + step);
+    __syncthreads();
+  }
+  float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = k0 + wk + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < a.M && col < a.K) out[(int64_t)row * a.K + col] = acc[i][j][r];
+      }
+    }
+}
+
+// dW[m, k] = sum over slabs of partial[b][m][k] in a fixed order (wave w of a block adds the slabs w, w + 4, ..
+// ascending for 64 consecutive outputs, then the four wave sums are added in wave order), rounded once to bfloat16.
+__global__ void __launch_bounds__(kBlock) k_sum_partials_bf16(const float* __restrict__ partial, int nslabs, int M, int K,
+                                                              bf16_t* __restrict__ dW, int64_t ldw) {
+  __shared__ float red[kBlock];
+  const int64_t count = (int64_t)M * K;
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < count; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + o;
+    float s = 0.f;
+    if (i < count)
+      for (int b = g; b < nslabs; b += kBlock / 64) s += partial[(int64_t)b * count + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (g == 0 && i < count) {
+      float tot = red[o];
+      for (int k = 1; k < kBlock / 64; ++k) tot += red[k * 64 + o];
+      dW[(i / K) * ldw + (i % K)] = f32_to_bf16(tot);
+    }
+    __syncthreads();
+  }
+}
+
+// Row-slab walkers (gridDim.x): four 40 KiB-LDS blocks per CU over all output tiles, but at least 8 slabs per
+// walker so that the partial tiles stay small next to the operands.
+static int tn_bf16_slabs(int64_t N, int M, int K) {
+  const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
+  int64_t slabs = 1024 / tiles;
+  const int64_t need = ((N + kTnRows - 1) / kTnRows + 7) / 8;
+  if (slabs > need) slabs = need;
+  if (slabs < 1) slabs = 1;
+  return (int)slabs;
+}
+
 }  // namespace mpnn
 
 using namespace mpnn;
@@ -248,5 +422,41 @@ extern "C" int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W
   else if (M <= 128) launch_nt_bf16<4, 1>(a, stream);
   else launch_nt_bf16<4, 2>(a, stream);
   MPNN_LAUNCH_CHECK("k_gemm_nt_bf16");
+  return MPNN_OK;
+}
+
+extern "C" int64_t mpnn_gemm_tn_bf16_scratch_floats(int64_t N, int32_t M, int32_t K) {
+  if (N < 0 || M < 1 || K < 1) return -1;
+  return (int64_t)tn_bf16_slabs(N, M, K) * M * K;
+}
+
+extern "C" int32_t mpnn_gemm_tn_bf16(const void* G, int64_t ldg, const void* mask, int64_t ldm, const void* X,
+                                     int64_t ldx, void* dW, int64_t lddw, float* scratch, void* Gout, int64_t ldgo,
+                                     int64_t N, int32_t M, int32_t K, mpnn_stream_t stream) {
+  if (N < 0 || M < 8 || K < 8) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: bad sizes");
+  if ((M | K) & 7) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: M and K must be multiples of 8");
+  if (!dW) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: dW is null");
+  if (lddw < K) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: lddw below K");
+  if (N == 0) {
+    MPNN_HIP_CHECK(hipMemset2DAsync(dW, (size_t)lddw * 2, 0, (size_t)K * 2, (size_t)M, stream));
+    return MPNN_OK;
+  }
+  if (!G || !X || !scratch) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: null pointer argument");
+  if (ldg < M || ldx < K || (mask && ldm < M) || (Gout && ldgo < M))
+    return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: leading dimension too small");
+  const uintptr_t ptrs = (uintptr_t)G | (uintptr_t)mask | (uintptr_t)X | (uintptr_t)Gout;
+  if ((ptrs & 15) || ((ldg | ldm | ldx | ldgo) & 7))
+    return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: operands must be 16-byte aligned with row strides that keep them so");
+  TnBf16Args a{static_cast<const bf16_t*>(G), ldg, static_cast<const bf16_t*>(mask), ldm, static_cast<const bf16_t*>(X), ldx,
+               static_cast<bf16_t*>(Gout), ldgo, scratch, N, M, K};
+  const int slabs = tn_bf16_slabs(N, M, K);
+  dim3 grid(slabs, (M + 127) / 128, (K + 127) / 128);
+  if (mask) k_gemm_tn_bf16<true><<<grid, kBlock, 0, stream>>>(a);
+  else k_gemm_tn_bf16<false><<<grid, kBlock, 0, stream>>>(a);
+  MPNN_LAUNCH_CHECK("k_gemm_tn_bf16");
+  int64_t blocks = ((int64_t)M * K + 63) / 64;
+  if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+  k_sum_partials_bf16<<<(int)blocks, kBlock, 0, stream>>>(scratch, slabs, M, K, static_cast<bf16_t*>(dW), lddw);
+  MPNN_LAUNCH_CHECK("k_sum_partials_bf16");
   return MPNN_OK;
 }

@@ -16,7 +16,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .dense import gemm_nt, gemm_nt_bf16, gemm_tn
+from .dense import gemm_nt, gemm_nt_bf16, gemm_tn, gemm_tn_bf16
 from .graph import MPGraph
 
 
@@ -72,8 +72,8 @@ class _LayerFn(torch.autograd.Function):
 
 class _LayerFnBf16(torch.autograd.Function):
     """The same node for bfloat16 models: bf16 storage, float32 accumulation.  The products with a huge row count
-    run on mpnn_gemm_nt_bf16; the three small weight-gradient products (reductions over the rows) go to the
-    library GEMM of torch; the relu backward is one elementwise pass."""
+    run on mpnn_gemm_nt_bf16, the three weight-gradient products (reductions over the rows) on mpnn_gemm_tn_bf16,
+    the first of which also leaves the relu-masked upstream gradient."""
 
     @staticmethod
     def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
@@ -100,17 +100,25 @@ class _LayerFnBf16(torch.autograd.Function):
         graph = ctx.graph
         f = x.size(1)
         h = wt.size(1)
-        gz = torch.ops.aten.threshold_backward(gy.contiguous(), y, 0)      # gy * [y > 0]
+        gy = gy if gy.is_contiguous() else gy.contiguous()
         g_ab = torch.empty_like(ab)
+        g_wout = torch.empty((h, f + h), dtype=gy.dtype, device=gy.device) if ctx.needs_input_grad[4] else None
+        # gz = gy * [y > 0] is a by-product of the first weight-gradient product (whole 256-byte rows)
+        if g_wout is not None and gy.data_ptr() % 16 == 0:
+            gz = torch.empty_like(gy)
+            gemm_tn_bf16(gy, x, mask=y, out=g_wout[:, :f], g_out=gz)
+        else:
+            gz = torch.ops.aten.threshold_backward(gy, y, 0)
+            if g_wout is not None:
+                g_wout[:, :f] = gz.t().mm(x)
         ga = gemm_nt_bf16(gz, wt[f:], emul=cnt, out2=g_ab[:, :h])
         g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = gemm_nt_bf16(gz, wt[:f], g_ab, w_nodes.t().contiguous())
-        g_wn = g_ab.t().mm(x) if ctx.needs_input_grad[2] else None
-        g_wout = None
-        if ctx.needs_input_grad[4]:
-            g_wout = torch.cat([gz.t().mm(x), gz.t().mm(aggr)], dim=1)
+        g_wn = gemm_tn_bf16(g_ab, x) if ctx.needs_input_grad[2] else None
+        if g_wout is not None:
+            gemm_tn_bf16(gz, aggr, out=g_wout[:, f:])
         return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
 
 

@@ -436,3 +436,50 @@ def test_bf16_layer_node_against_the_oracle(mode, n, e, f, h, fe):
     assert_close(xg.grad.float(), xc.grad, RTOL16, atol_scale=2.0, what="grad x")
     for k, p in layer.named_parameters():
         assert_close(p.grad.float(), params[k].grad, RTOL16, atol_scale=2.0, what=f"grad {k}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k1,k2,m,relu", [(5000, 128, 0, 256, False), (3001, 128, 128, 128, True), (77, 8, 24, 40, True)])
+def test_gemm_nt_bf16(n, k1, k2, m, relu):
+    """bf16 operands, float32 accumulation: the float64 product of the same bf16 values, rounded once to bf16."""
+    from mpnn_amd.dense import gemm_nt_bf16
+    gen = torch.Generator().manual_seed(n + m)
+    bf = lambda *s: torch.randn(*s, generator=gen).bfloat16()
+    x1, w = bf(n, k1), bf(m, k1 + k2)
+    x2 = bf(n, k2) if k2 else None
+    emul = torch.rand(n, m, generator=gen)
+    want = x1.double() @ w[:, :k1].double().t()
+    if k2:
+        want = want + x2.double() @ w[:, k1:].double().t()
+    if relu:
+        want = want.relu()
+    wd = w.cuda()
+    out2 = torch.zeros(n, m + 8, dtype=torch.bfloat16, device="cuda")
+    got = gemm_nt_bf16(x1.cuda(), wd[:, :k1].contiguous(), x2.cuda() if k2 else None,
+                       wd[:, k1:].contiguous() if k2 else None, relu=relu, emul=emul.cuda(), out2=out2[:, :m])
+    # one bf16 rounding of an (almost) exact sum: half an ulp = 2^-9 relative, plus the float32 accumulation noise
+    assert_close(got.float(), want, 2.0 ** -8, what="gemm_nt_bf16")
+    assert_close(out2[:, :m].float(), got.float().cpu().double() * emul.double(), 2.0 ** -8, what="gemm_nt_bf16 second output")
+    assert float(out2[:, m:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m,k", [(5000, 256, 128), (3001, 64, 504), (100, 64, 16), (33, 8, 8), (4096, 128, 136)])
+def test_gemm_tn_bf16(n, m, k):
+    from mpnn_amd.dense import gemm_tn_bf16
+    gen = torch.Generator().manual_seed(n + k)
+    bf = lambda *s: torch.randn(*s, generator=gen).bfloat16()
+    g, x, mask = bf(n, m), bf(n, k), bf(n, m).relu()          # a relu output as the mask: zeros and positives
+    mask[0, 0] = -0.0
+    gz = g.double() * (mask.double() > 0)
+    want = gz.t() @ x.double()
+    wide = torch.zeros(m, k + 8, dtype=torch.bfloat16, device="cuda")
+    g_out = torch.empty(n, m, dtype=torch.bfloat16, device="cuda")
+    got = gemm_tn_bf16(g.cuda(), x.cuda(), mask=mask.cuda(), out=wide[:, 8:], g_out=g_out)
+    assert_close(got.float(), want, 2.0 ** -8, what="gemm_tn_bf16")
+    assert float(wide[:, :8].abs().sum()) == 0.0
+    assert torch.equal(g_out.cpu().double(), gz), "masked gradient by-product"
+    again = gemm_tn_bf16(g.cuda(), x.cuda(), mask=mask.cuda())
+    assert torch.equal(again, got.contiguous()), "weight gradient is not bitwise reproducible"
+    plain = gemm_tn_bf16(g.cuda(), x.cuda())
+    assert_close(plain.float(), g.double().t() @ x.double(), 2.0 ** -8, what="gemm_tn_bf16 unmasked")
