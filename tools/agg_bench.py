@@ -15,6 +15,13 @@ if kind == "powerlaw":
     d = synth.powerlaw(dev, 0, n, e, 8, 4)
 else:
     d = {"edge_index": torch.randint(0, n, (2, e), device=dev), "edge_attr": torch.rand(e, 4, device=dev)}
+order = os.environ.get("AGG_ORDER", "")
+if order:   # experiment: edge order inside each row of the two sorted structures
+    ei = d["edge_index"]
+    perm = torch.argsort(ei[0] if order == "src" else ei[0] + ei[1], stable=True) if order in ("src", "sum") else torch.randperm(e, device=dev)
+    if order == "both":   # forward rows ascending in src AND transpose rows ascending in dst: sort by (src, dst) pairs
+        perm = torch.argsort(ei[1], stable=True); perm = perm[torch.argsort(ei[0][perm], stable=True)]
+    d["edge_index"] = ei[:, perm].contiguous(); d["edge_attr"] = d["edge_attr"][perm].contiguous()
 g = MPGraph(d["edge_index"], n)
 ab = torch.randn(n, 2 * H, device=dev, requires_grad=True)
 we = torch.randn(H, 4, device=dev, requires_grad=True)
