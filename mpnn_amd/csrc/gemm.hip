@@ -92,11 +92,12 @@ __device__ __forceinline__ float4 relu_mask4(float4 v, float4 m) {
 // 4-byte, whole-line pattern of the plain layout is faster.
 //
 // SPLIT computes the same float32 products on the bfloat16 matrix cores, which run 16 times the rate of the
-// float32 ones: every operand value v is written to LDS as three bfloat16 pieces v = v1 + v2 + v3 (v1 = bf16(v),
-// v2 = bf16(v - v1), v3 = bf16(v - v1 - v2); the three 8-bit significands hold all 24 bits of v, the sum is
-// exact), and a product x*w is accumulated in float32 as x3*w1 + x1*w3 + x2*w2 + x2*w1 + x1*w2 + x1*w1 - the
-// dropped terms are below 2^-32 of |x*w|.  Each piece product is exact in float32, so the result carries float32
-// rounding of the accumulation only (measured: error against float64 no larger than the float32 MFMA's).
+// float32 ones: every operand value v is written to LDS as three bfloat16 pieces v = v1 + v2 + v3 (v1 = the upper
+// 16 bits of v, v2 = the upper 16 bits of v - v1, v3 = v - v1 - v2; the three 8-bit significands hold all 24 bits
+// of v, the sum is exact), and a product x*w is accumulated in float32 as x3*w1 + x1*w3 + x2*w2 + x2*w1 + x1*w2 +
+// x1*w1 - the dropped terms (x2*w3, x3*w2, x3*w3) are at most 2^-23, typically 2^-25, of |x*w|, i.e. at the level
+// of one float32 rounding.  Each piece product is exact in float32 (measured: error against float64 no larger
+// than the float32 MFMA's).
 // k-chunks are 16 wide (one v_mfma_f32_32x32x16_bf16 step); an LDS row is 3 pieces x 16 k x 2 B + 16 B pad.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -115,15 +116,19 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, b);
 }
 
-// The three bfloat16 pieces of 4 consecutive floats, each as 4 packed values (8 bytes).
+// The three bfloat16 pieces of 4 consecutive floats, each as 4 packed values (8 bytes).  A piece is the upper
+// half of the float (truncation); the remainder after taking 8 significant bits away is exact in float32, and
+// the third remainder has at most 8 significant bits left, so v1 + v2 + v3 == v exactly.  Only full-rate
+// integer/float instructions: one v_perm_b32 packs the upper halves of two floats.
 __device__ __forceinline__ void split4(float4 v, uint2 (&p)[3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    p[i].x = pack_bf16(v.x, v.y);
-    p[i].y = pack_bf16(v.z, v.w);
-    if (i < 2) {   // remainders are exact in float32
-      v.x -= __uint_as_float(p[i].x << 16); v.y -= __uint_as_float(p[i].x & 0xffff0000u);
-      v.z -= __uint_as_float(p[i].y << 16); v.w -= __uint_as_float(p[i].y & 0xffff0000u);
+    const uint32_t ux = __float_as_uint(v.x), uy = __float_as_uint(v.y), uz = __float_as_uint(v.z), uw = __float_as_uint(v.w);
+    p[i].x = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+    p[i].y = __builtin_amdgcn_perm(uw, uz, 0x07060302u);
+    if (i < 2) {
+      v.x -= __uint_as_float(ux & 0xffff0000u); v.y -= __uint_as_float(uy & 0xffff0000u);
+      v.z -= __uint_as_float(uz & 0xffff0000u); v.w -= __uint_as_float(uw & 0xffff0000u);
     }
   }
 }
@@ -460,10 +465,31 @@ struct TnArgs {
   int64_t N; int M; int K;
 };
 
-// Output tile 128 (m) x 128 (k) per block; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles).
-// Row slabs are software-pipelined like the k-chunks of k_gemm_nt (two LDS buffers, one barrier per slab).
-template <bool ALIGNED>
-__global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
+#ifndef MPNN_TN_DEPTH
+#define MPNN_TN_DEPTH 2
+#endif
+constexpr int kTnDepth = MPNN_TN_DEPTH;   // register sets of the slab ring of k_gemm_tn (split, unmasked form)
+
+// The three bfloat16 pieces of 8 floats, each piece as one MFMA operand.
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&p)[3]) {
+  uint2 lo[3], hi[3];
+  split4(make_float4(v[0], v[1], v[2], v[3]), lo);
+  split4(make_float4(v[4], v[5], v[6], v[7]), hi);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) p[i] = __builtin_bit_cast(bf16x8, make_uint4(lo[i].x, lo[i].y, hi[i].x, hi[i].y));
+}
+
+// Output tile 128 (m) x 128 (k) per block; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles); 32-row slabs
+// alternate between two LDS buffers with one barrier per slab.
+// SPLIT: the float32 slabs lie in LDS as loaded; a lane reads the 8 contraction values of its output column with
+// 4-byte LDS reads (lane half h, value j = row 2 j + h of the 16-row step: the order inside one MFMA is free as
+// long as both operands share it), splits them into three bfloat16 pieces in registers and multiplies on the
+// bfloat16 matrix cores (six piece products, as in k_gemm_nt).
+// Row slabs run through a ring of D register sets (the slab being multiplied is in LDS, the next D - 1 are in
+// flight; every load is issued unconditionally with clamped rows so that the wait counts keep the ring full).
+template <bool ALIGNED, bool SPLIT, bool MASKED>
+__global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
+  constexpr int D = kTnDepth > 2 && SPLIT && !MASKED ? kTnDepth : 2;
   __shared__ float Gs[2][32][128];
   __shared__ float Xs[2][32][128];
   const int tid = threadIdx.x;
@@ -481,63 +507,123 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn(TnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 gr[4], mr[4], xr[4];
-  int gv[4], xv[4];
-  auto fetch = [&](int64_t n0) {
+  // a thread moves 4 float4 per matrix and slab: rows tid/32 + 8 q, columns 4 (tid % 32) ..
+  const int pr = tid >> 5, pc = (tid & 31) * 4;
+  float4 gr[D][4], mr[MASKED ? D : 1][4], xr[D][4];
+  auto fetch = [&](auto S, int64_t n0) {
+    constexpr int st = decltype(S)::value;
+    if constexpr (ALIGNED) {   // scalar slab base + 32-bit lane offsets (a slab spans < 2^31 elements)
+      const int64_t left = a.N - 1 - n0;
+      const int rt_max = left < 31 ? (left < 0 ? 0 : (int)left) : 31;
+      const int64_t rbase = n0 < a.N ? n0 : a.N - 1;
+      const float* gb = a.G + rbase * a.ldg;
+      const float* mb = MASKED ? a.mask + rbase * a.ldm : nullptr;
+      const float* xb = a.X + rbase * a.ldx;
+      const uint32_t gc = m0 + pc < a.M ? m0 + pc : a.M - 4, xc = k0 + pc < a.K ? k0 + pc : a.K - 4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {  // 32 rows x 32 float4 per matrix
-      const int idx = tid + kBlock * q;
-      const int c4 = (idx & 31) * 4;
-      int64_t row = n0 + (idx >> 5);
-      const bool row_ok = row < a.N;   // rows past the end must contribute exact zeros to the sums
-      row = row_ok ? row : a.N - 1;
-      gr[q] = load_chunk4<ALIGNED>(a.G + row * a.ldg, m0 + c4, a.M);
-      if (a.mask) mr[q] = load_chunk4<ALIGNED>(a.mask + row * a.ldm, m0 + c4, a.M);
-      xr[q] = load_chunk4<ALIGNED>(a.X + row * a.ldx, k0 + c4, a.K);
-      gv[q] = valid4(m0 + c4, a.M, row_ok);
-      xv[q] = valid4(k0 + c4, a.K, row_ok);
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t r = pr + 8 * q < rt_max ? pr + 8 * q : rt_max;
+        gr[st][q] = *reinterpret_cast<const float4*>(gb + (r * (uint32_t)a.ldg + gc));
+        if constexpr (MASKED) mr[st][q] = *reinterpret_cast<const float4*>(mb + (r * (uint32_t)a.ldm + gc));
+        xr[st][q] = *reinterpret_cast<const float4*>(xb + (r * (uint32_t)a.ldx + xc));
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int64_t row = n0 + pr + 8 * q;
+        row = row < a.N ? row : a.N - 1;
+        gr[st][q] = load_chunk4<ALIGNED>(a.G + row * a.ldg, m0 + pc, a.M);
+        if constexpr (MASKED) mr[st][q] = load_chunk4<ALIGNED>(a.mask + row * a.ldm, m0 + pc, a.M);
+        xr[st][q] = load_chunk4<ALIGNED>(a.X + row * a.ldx, k0 + pc, a.K);
+      }
     }
   };
-  auto stash = [&](int buf, int64_t nslab) {
+  auto stash = [&](auto S, int buf, int64_t nslab) {
+    constexpr int st = decltype(S)::value;
     const bool emit = ALIGNED && a.gout && blockIdx.z == 0;   // uniform
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int idx = tid + kBlock * q;
-      float4 g = select4(gr[q], gv[q]);
-      if (a.mask) g = relu_mask4(g, mr[q]);
+      const int r = pr + 8 * q;
+      const bool row_ok = nslab + r < a.N;   // rows past the end must contribute exact zeros to the sums
+      float4 g = select4(gr[st][q], valid4(m0 + pc, a.M, row_ok));
+      if constexpr (MASKED) g = relu_mask4(g, mr[st][q]);
       if (emit) {   // the masked gradient, one whole 512-byte row per 32 lanes
-        const int64_t row = nslab + (idx >> 5);
-        const int col = m0 + (idx & 31) * 4;
-        if (row < a.N && col < a.M) *reinterpret_cast<float4*>(a.gout + row * a.ldgo + col) = g;
+        if (row_ok && m0 + pc < a.M) *reinterpret_cast<float4*>(a.gout + (nslab + r) * a.ldgo + m0 + pc) = g;
       }
-      *reinterpret_cast<float4*>(&Gs[buf][idx >> 5][(idx & 31) * 4]) = g;
-      *reinterpret_cast<float4*>(&Xs[buf][idx >> 5][(idx & 31) * 4]) = select4(xr[q], xv[q]);
+      *reinterpret_cast<float4*>(&Gs[buf][r][pc]) = g;
+      *reinterpret_cast<float4*>(&Xs[buf][r][pc]) = select4(xr[st][q], valid4(k0 + pc, a.K, row_ok));
+    }
+  };
+  auto multiply = [&](int buf) {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 ap[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          float av[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) av[j] = Gs[buf][16 * t + 2 * j + lh][wm + 32 * i + li];
+          split8(av, ap[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float bv[8];
+          bf16x8 bp[3];
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) bv[jj] = Xs[buf][16 * t + 2 * jj + lh][wk + 32 * j + li];
+          split8(bv, bp);
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {   // smallest terms first
+            f32x16 c = acc[i][j];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[1], c, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int n = 2 * t + lh;
+        const float a0 = Gs[buf][n][wm + li], a1 = Gs[buf][n][wm + 32 + li];
+        const float b0 = Xs[buf][n][wk + li], b1 = Xs[buf][n][wk + 32 + li];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
     }
   };
 
   const int64_t step = (int64_t)gridDim.x * 32;
-  int64_t n0 = (int64_t)blockIdx.x * 32;
-  int buf = 0;
-  if (n0 < a.N) {
-    fetch(n0);
-    stash(0, n0);
-  }
-  __syncthreads();
-  for (; n0 < a.N; n0 += step, buf ^= 1) {
-    const bool more = n0 + step < a.N;
-    if (more) fetch(n0 + step);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int n = 2 * t + lh;
-      const float a0 = Gs[buf][n][wm + li], a1 = Gs[buf][n][wm + 32 + li];
-      const float b0 = Xs[buf][n][wk + li], b1 = Xs[buf][n][wk + 32 + li];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-    if (more) stash(buf ^ 1, n0 + step);
+  const int64_t first = (int64_t)blockIdx.x * 32;
+  const int64_t total = first < a.N ? (a.N - first + step - 1) / step : 0;   // slabs of this block
+  auto body = [&](auto S, int64_t it) {
+    constexpr int st = decltype(S)::value;   // == it % D: the set slab `it` left when it was stashed
+    using Next = std::integral_constant<int, (st + 1) % D>;
+    const int64_t n0 = first + it * step;
+    const int buf = (int)(it & 1);
+    fetch(S, n0 + D * step);
+    multiply(buf);
+    if (it + 1 < total) stash(Next{}, buf ^ 1, n0 + step);
     __syncthreads();
+  };
+  if (total > 0) {   // uniform over the block
+    fetch(std::integral_constant<int, 0>{}, first);
+    fetch(std::integral_constant<int, 1>{}, first + step);
+    if constexpr (D > 2) fetch(std::integral_constant<int, 2>{}, first + 2 * step);
+    stash(std::integral_constant<int, 0>{}, 0, first);
+    __syncthreads();
+    for (int64_t it = 0; it < total; it += D) {
+      body(std::integral_constant<int, 0>{}, it);
+      if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
+      if constexpr (D > 2)
+        if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
+    }
   }
   float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
 #pragma unroll
@@ -690,8 +776,10 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
   if (Gout && (!aligned || ldgo < M || ((uintptr_t)Gout & 15) || (ldgo & 3)))
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: Gout needs 16-byte aligned operands and ldgo >= M");
   dim3 grid(slabs, (M + 127) / 128, (K + 127) / 128);
-  if (aligned) k_gemm_tn<true><<<grid, kBlock, 0, stream>>>(a);
-  else k_gemm_tn<false><<<grid, kBlock, 0, stream>>>(a);
+  auto go = [&](auto kern) { kern<<<grid, kBlock, 0, stream>>>(a); };
+  if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true>) : go(k_gemm_tn<true, true, false>);
+  else if (aligned) mask ? go(k_gemm_tn<true, false, true>) : go(k_gemm_tn<true, false, false>);
+  else mask ? go(k_gemm_tn<false, false, true>) : go(k_gemm_tn<false, false, false>);
   MPNN_LAUNCH_CHECK("k_gemm_tn");
   int64_t blocks = ((int64_t)M * K + 63) / 64;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
