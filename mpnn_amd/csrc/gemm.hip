@@ -639,6 +639,166 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
     }
 }
 
+// The split form with hardware-transposed fragment reads (aligned operands).  Slabs of 16 rows are split into
+// their three bfloat16 pieces once, when they are written to LDS (piece planes [16 rows][128 columns] of bf16,
+// 288-byte row pitch), and ds_read_b64_tr_b16 hands every lane 4 contraction values of its output column per
+// read: inside a group of 16 lanes, lane 4a + c receives element c of the 8-byte rows addressed by lanes
+// a, a + 4, a + 8, a + 12.  Lanes a + 4k therefore address row k of a 4-row block at columns 4a .. 4a + 3, and
+// the group ends up with 16 consecutive columns x 4 rows.  Lane half h takes rows 8h .. 8h + 7 of the slab in two
+// reads, which is the operand layout of v_mfma_f32_32x32x16_bf16.  The multiply loop has no VALU work left.
+constexpr int kTrRows = 16;
+constexpr int kTrPitch = 128 * 2 + 32;            // bytes; 4 consecutive rows start 8 banks apart
+constexpr int kTrPlane = kTrRows * kTrPitch;      // one piece of one matrix
+constexpr int kTrStage = 6 * kTrPlane;            // 3 pieces of G, 3 pieces of X
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
+
+__device__ __forceinline__ bf16x8 read_tr8(const char* p) {   // rows +0..3 and +4..7 of the lane's 8
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 4 * kTrPitch));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <bool MASKED>
+__global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
+  constexpr int D = MASKED ? 3 : 4;
+  __shared__ __attribute__((aligned(16))) char lds[2 * kTrStage];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
+  const int m0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // a thread moves 2 float4 per matrix and slab: rows tid/32 + 8 q, columns 4 (tid % 32) ..
+  const int pr = tid >> 5, pc = (tid & 31) * 4;
+  const bool cols_full = m0 + 128 <= a.M && k0 + 128 <= a.K;
+  const uint32_t gc = m0 + pc < a.M ? m0 + pc : a.M - 4, xc = k0 + pc < a.K ? k0 + pc : a.K - 4;
+  float4 gr[D][2], mr[MASKED ? D : 1][2], xr[D][2];
+  auto fetch = [&](auto S, int64_t n0) {   // scalar slab base + 32-bit lane offsets
+    constexpr int st = decltype(S)::value;
+    const int64_t left = a.N - 1 - n0;
+    const int rt_max = left < kTrRows - 1 ? (left < 0 ? 0 : (int)left) : kTrRows - 1;
+    const int64_t rbase = n0 < a.N ? n0 : a.N - 1;
+    const float* gb = a.G + rbase * a.ldg;
+    const float* mb = MASKED ? a.mask + rbase * a.ldm : nullptr;
+    const float* xb = a.X + rbase * a.ldx;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t r = pr + 8 * q < rt_max ? pr + 8 * q : rt_max;
+      gr[st][q] = *reinterpret_cast<const float4*>(gb + (r * (uint32_t)a.ldg + gc));
+      if constexpr (MASKED) mr[st][q] = *reinterpret_cast<const float4*>(mb + (r * (uint32_t)a.ldm + gc));
+      xr[st][q] = *reinterpret_cast<const float4*>(xb + (r * (uint32_t)a.ldx + xc));
+    }
+  };
+  auto stash = [&](auto S, int buf, int64_t nslab) {
+    constexpr int st = decltype(S)::value;
+    const bool emit = a.gout && blockIdx.z == 0;                  // uniform
+    const bool full = cols_full && nslab + kTrRows <= a.N;        // uniform: nothing to zero
+    char* base = lds + buf * kTrStage;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = pr + 8 * q;
+      float4 g = gr[st][q], x = xr[st][q];
+      if (!full) {   // rows and columns past the end must contribute exact zeros to the sums
+        const bool row_ok = nslab + r < a.N;
+        g = select4(g, valid4(m0 + pc, a.M, row_ok));
+        x = select4(x, valid4(k0 + pc, a.K, row_ok));
+      }
+      if constexpr (MASKED) g = relu_mask4(g, mr[st][q]);
+      if (emit && nslab + r < a.N && m0 + pc < a.M)   // the masked gradient, one whole 512-byte row per 32 lanes
+        *reinterpret_cast<float4*>(a.gout + (nslab + r) * a.ldgo + m0 + pc) = g;
+      uint2 gp[3], xp[3];
+      split4(g, gp);
+      split4(x, xp);
+      char* dst = base + r * kTrPitch + pc * 2;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        *reinterpret_cast<uint2*>(dst + i * kTrPlane) = gp[i];
+        *reinterpret_cast<uint2*>(dst + (3 + i) * kTrPlane) = xp[i];
+      }
+    }
+  };
+  // this lane's address inside a 32-column tile of a piece plane (see the header comment)
+  const int s16 = lane & 15;
+  const int frag_off = (8 * lh + (s16 >> 2)) * kTrPitch + (16 * ((lane >> 4) & 1) + 4 * (s16 & 3)) * 2;
+  auto multiply = [&](int buf) {
+    const char* gbase = lds + buf * kTrStage + frag_off + wm * 2;
+    const char* xbase = lds + buf * kTrStage + 3 * kTrPlane + frag_off + wk * 2;
+    bf16x8 ap[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ap[i][p] = read_tr8(gbase + p * kTrPlane + i * 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 bp[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bp[p] = read_tr8(xbase + p * kTrPlane + j * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {   // smallest terms first
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[1], c, 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
+      }
+    }
+  };
+
+  const int64_t step = (int64_t)gridDim.x * kTrRows;
+  const int64_t first = (int64_t)blockIdx.x * kTrRows;
+  const int64_t total = first < a.N ? (a.N - first + step - 1) / step : 0;   // slabs of this block
+  auto body = [&](auto S, int64_t it) {
+    constexpr int st = decltype(S)::value;   // == it % D: the set slab `it` left when it was stashed
+    using Next = std::integral_constant<int, (st + 1) % D>;
+    const int64_t n0 = first + it * step;
+    const int buf = (int)(it & 1);
+    fetch(S, n0 + D * step);
+    multiply(buf);
+    if (it + 1 < total) stash(Next{}, buf ^ 1, n0 + step);
+    __syncthreads();
+  };
+  if (total > 0) {   // uniform over the block
+    fetch(std::integral_constant<int, 0>{}, first);
+    fetch(std::integral_constant<int, 1>{}, first + step);
+    fetch(std::integral_constant<int, 2>{}, first + 2 * step);
+    if constexpr (D > 3) fetch(std::integral_constant<int, 3>{}, first + 3 * step);
+    stash(std::integral_constant<int, 0>{}, 0, first);
+    __syncthreads();
+    for (int64_t it = 0; it < total; it += D) {
+      body(std::integral_constant<int, 0>{}, it);
+      if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
+      if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
+      if constexpr (D > 3)
+        if (it + 3 < total) body(std::integral_constant<int, 3>{}, it + 3);
+    }
+  }
+  float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = k0 + wk + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < a.M && col < a.K) out[(int64_t)row * a.K + col] = acc[i][j][r];
+      }
+    }
+}
+
 // dW[m, k] = sum over slabs of partial[b][m][k] in a fixed order: each wave of a block takes the slabs
 // b = wave, wave + 4, ... (ascending) for 64 consecutive outputs, then the four wave sums are added in wave order.
 __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int nslabs, int M, int K,
@@ -668,7 +828,7 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict
 static int tn_slabs(int64_t N, int M, int K) {
   const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
   int64_t slabs = 512 / tiles;
-  const int64_t need = ((N + 31) / 32 + 7) / 8;
+  const int64_t need = ((N + 31) / 32 + 7) / 8;   // in 32-row units whatever the kernel's slab height
   if (slabs > need) slabs = need;
   if (slabs < 1) slabs = 1;
   return (int)slabs;
@@ -679,6 +839,13 @@ static int tn_slabs(int64_t N, int M, int K) {
 static bool gemm_split() {
   const char* e = getenv("MPNN_GEMM");
   return !(e && (e[0] == 'f' || e[0] == 'F'));
+}
+
+// MPNN_GEMM_TN=regs keeps the split weight-gradient form that splits in registers after 4-byte LDS reads
+// (kept for comparison); the default splits once on the way into LDS and reads fragments transposed.
+static bool tn_lds_split() {
+  const char* e = getenv("MPNN_GEMM_TN");
+  return e && e[0] == 'r';
 }
 
 static bool nt_aligned(const NtArgs& a) {
@@ -777,7 +944,8 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: Gout needs 16-byte aligned operands and ldgo >= M");
   dim3 grid(slabs, (M + 127) / 128, (K + 127) / 128);
   auto go = [&](auto kern) { kern<<<grid, kBlock, 0, stream>>>(a); };
-  if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true>) : go(k_gemm_tn<true, true, false>);
+  if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true>) : go(k_gemm_tn_tr<false>);
+  else if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true>) : go(k_gemm_tn<true, true, false>);
   else if (aligned) mask ? go(k_gemm_tn<true, false, true>) : go(k_gemm_tn<true, false, false>);
   else mask ? go(k_gemm_tn<false, false, true>) : go(k_gemm_tn<false, false, false>);
   MPNN_LAUNCH_CHECK("k_gemm_tn");
