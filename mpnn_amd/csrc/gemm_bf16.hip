@@ -226,12 +226,16 @@ static void launch_nt_bf16(const NtBf16Args& a, hipStream_t stream) {
 //
 // The contraction runs over the rows, which are the slow index of both operands, while a lane of
 // v_mfma_f32_32x32x16_bf16 wants 8 contraction values of one output row.  Slabs of 32 rows go to LDS as they
-// lie in memory (16-byte stores) and every lane collects its 8 values with 16-bit LDS reads.  The order of the
-// contraction values inside one instruction is free as long as both operands use the same one: lane half h,
-// value j stands for row 2 j + h of the 16-row step, so the two halves read adjacent LDS rows, which the
-// 320-byte row pitch (80 dwords = 16 mod 32) puts on disjoint banks.
+// lie in memory (16-byte stores) and ds_read_b64_tr_b16 hands every lane 4 contraction values of its output
+// column per read: inside a group of 16 lanes, lane 4a + c receives element c of the 8-byte rows addressed by
+// lanes a, a + 4, a + 8, a + 12, so lanes a + 4k address row k of a 4-row block at columns 4a .. 4a + 3 and the
+// group ends up with 16 consecutive columns x 4 rows.  Lane half h takes rows 8h .. 8h + 7 of a 16-row step in
+// two reads.  288-byte row pitch: 4 consecutive rows start 8 banks apart.
 constexpr int kTnRows = 32;
-constexpr int kTnRowB = 128 * 2 + 64;
+constexpr int kTnRowB = 128 * 2 + 32;
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) bf16x4* lds_bf16x4_ptr;
 
 struct TnBf16Args {
   const bf16_t* G; int64_t ldg;      // [N, M]
@@ -250,16 +254,11 @@ __device__ __forceinline__ uint32_t relu_mask2(uint32_t g, uint32_t y) {
   return g & ((keep_lo ? 0xffffu : 0u) | (keep_hi ? 0xffff0000u : 0u));
 }
 
-// 8 contraction values of one output column: 16-bit LDS reads two rows apart, packed in pairs.
+// 8 contraction values of one output column: rows +0..3 and +4..7 of the lane's 8.
 __device__ __forceinline__ bf16x8 read_col8(const char* p) {
-  uint32_t w[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const uint32_t lo = *reinterpret_cast<const uint16_t*>(p + (4 * q) * kTnRowB);
-    const uint32_t hi = *reinterpret_cast<const uint16_t*>(p + (4 * q + 2) * kTnRowB);
-    w[q] = lo | (hi << 16);
-  }
-  return __builtin_bit_cast(bf16x8, make_uint4(w[0], w[1], w[2], w[3]));
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 4 * kTnRowB));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // Output tile 128 (m) x 128 (k) per block; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles); blockIdx.x
@@ -318,6 +317,9 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
     }
   };
 
+  // this lane's address inside a 32-column tile of a 16-row step (see the header comment)
+  const int s16 = lane & 15;
+  const int frag_off = (8 * lh + (s16 >> 2)) * kTnRowB + (16 * ((lane >> 4) & 1) + 4 * (s16 & 3)) * 2;
   const int64_t step = (int64_t)gridDim.x * kTnRows;
   int64_t n0 = (int64_t)blockIdx.x * kTnRows;
   int buf = 0;
@@ -329,8 +331,8 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
   for (; n0 < a.N; n0 += step, buf ^= 1) {
     const bool more = n0 + step < a.N;
     if (more) fetch(n0 + step);
-    const char* gp = &Gs[buf][lh * kTnRowB + (wm + li) * 2];
-    const char* xp = &Xs[buf][lh * kTnRowB + (wk + li) * 2];
+    const char* gp = &Gs[buf][frag_off + wm * 2];
+    const char* xp = &Xs[buf][frag_off + wk * 2];
 #pragma unroll
     for (int s = 0; s < kTnRows / 16; ++s) {
       const bf16x8 a0 = read_col8(gp + s * 16 * kTnRowB), a1 = read_col8(gp + s * 16 * kTnRowB + 64);
