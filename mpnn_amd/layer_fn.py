@@ -21,13 +21,18 @@ from .graph import MPGraph
 
 
 class _LayerFn(torch.autograd.Function):
+    """``halo`` (partitioned graphs, see partition.Halo): the rows of x are this rank's destination range, the
+    source-side projection is exchanged across the ranks before the edge pass and its gradient summed back to the
+    owners after the backward edge pass; everything else is local."""
+
     @staticmethod
-    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
+    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=None):
         x = x if x.is_contiguous() else x.contiguous()
         f = x.size(1)
         h = w_out.size(0)
         ab = gemm_nt(x, w_nodes)
-        a, b = ab[:, :h], ab[:, h:]
+        a = ab[:, :h]
+        b = ab[:, h:] if halo is None else halo.gather(ab[:, h:])
         ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
         w_edge_c = w_edge.contiguous()
         want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
@@ -36,14 +41,16 @@ class _LayerFn(torch.autograd.Function):
         if want:
             if maskbits is not None:
                 graph.tpos
-            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge_c, w_out)
-            ctx.graph = graph
+            # the gathered source table is only read again by the recomputing backward
+            b_all = b if (halo is not None and maskbits is None) else None
+            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge_c, w_out, b_all)
+            ctx.graph, ctx.halo = graph, halo
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
-        graph = ctx.graph
+        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, b_all = ctx.saved_tensors
+        graph, halo = ctx.graph, ctx.halo
         f = x.size(1)
         h = w_out.size(0)
         gy = gy if gy.is_contiguous() else gy.contiguous()
@@ -60,14 +67,19 @@ class _LayerFn(torch.autograd.Function):
         elif g_wout is not None:
             gemm_tn(gy, x, mask=y, out=g_wout[:, :f])
         ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt, out2=g_ab[:, :h])
-        g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
+        if halo is None:
+            g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
+        else:   # gradient for every source row this rank's edges read, then summed back to the owners
+            gb_all = torch.empty((graph.num_src, h), dtype=ab.dtype, device=ab.device)
+            g_we = ops._run_backward_src(ab[:, :h], b_all, ga, ea_t, w_edge, graph.by_src, graph, gb_all, maskbits)
+            halo.scatter_sum(gb_all, g_ab[:, h:])
         gx = None
         if ctx.needs_input_grad[0]:
             gx = gemm_nt(g, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=m)
         g_wn = gemm_tn(g_ab, x) if ctx.needs_input_grad[2] else None
         if g_wout is not None:
             gemm_tn(g, aggr, mask=m, out=g_wout[:, f:])
-        return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
+        return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None, None
 
 
 class _LayerFnBf16(torch.autograd.Function):
@@ -136,6 +148,9 @@ def supported(x, edge_attr, *weights) -> bool:
 
 
 @torch.compiler.disable
-def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph) -> torch.Tensor:
-    fn = _LayerFnBf16 if x.dtype == torch.bfloat16 else _LayerFn
-    return fn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)
+def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=None) -> torch.Tensor:
+    if x.dtype == torch.bfloat16:
+        if halo is not None:
+            raise NotImplementedError("the bfloat16 layer node has no halo exchange")
+        return _LayerFnBf16.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)
+    return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph, halo)

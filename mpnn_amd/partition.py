@@ -18,7 +18,7 @@ import torch
 import torch.distributed as dist
 import torch.nn.functional as F
 
-from . import dense, ops
+from . import dense, layer_fn, ops
 from .graph import MPGraph
 from .layers import MPNNLayerCat, MPNNLayerSum, _update
 
@@ -125,6 +125,38 @@ class _HaloAllGather(torch.autograd.Function):
         return out[:ctx.n_local], None, None, None
 
 
+class Halo:
+    """The two exchanges of a partitioned layer as plain calls (used inside the fused layer node, which carries
+    its own backward): gather() = forward of _HaloAllGather, scatter_sum() = its backward."""
+
+    def __init__(self, pg: PartitionedGraph, group=None):
+        self.n_local, self.n_pad, self.world, self.group = pg.n_local, pg.n_pad, pg.world, group
+
+    def gather(self, b_local: torch.Tensor) -> torch.Tensor:
+        """[n_local, H] (any row stride) -> [world * n_pad, H], rank q's rows at q * n_pad."""
+        h = b_local.size(1)
+        send = b_local
+        if self.n_local != self.n_pad or not b_local.is_contiguous():
+            send = b_local.new_empty((self.n_pad, h))
+            send[:self.n_local] = b_local
+            if self.n_local != self.n_pad:
+                send[self.n_local:].zero_()
+        out = b_local.new_empty((self.world * self.n_pad, h))
+        _all_gather_into(out, send, self.group)
+        return out
+
+    def scatter_sum(self, g_all: torch.Tensor, out: torch.Tensor) -> None:
+        """out[n_local, H] (any row stride) = this rank's rows of the sum of every rank's g_all."""
+        if dist.get_backend(self.group) == "gloo":   # gloo has no reduce-scatter: all-reduce, then keep the own slice
+            _all_reduce_sum(g_all, self.group)
+            r = dist.get_rank(self.group)
+            mine = g_all[r * self.n_pad:(r + 1) * self.n_pad]
+        else:
+            mine = g_all.new_empty((self.n_pad, g_all.size(1)))
+            dist.reduce_scatter_tensor(mine, g_all, op=dist.ReduceOp.SUM, group=self.group)
+        out.copy_(mine[:self.n_local])
+
+
 def halo_all_gather(b_local: torch.Tensor, pg: PartitionedGraph, group=None) -> torch.Tensor:
     if pg.world == 1:
         return b_local
@@ -134,17 +166,21 @@ def halo_all_gather(b_local: torch.Tensor, pg: PartitionedGraph, group=None) -> 
 def partitioned_layer(layer, x_local: torch.Tensor, pg: PartitionedGraph, edge_attr_local: torch.Tensor,
                       group=None, aggregate_fn=None) -> torch.Tensor:
     """One MPNN layer on the local destination range (same arithmetic as layer.forward on the whole graph)."""
-    aggregate_fn = aggregate_fn or ops.aggregate
     if isinstance(layer, MPNNLayerSum):
-        ab = dense.project(x_local, layer.fused_linear.weight)
-        w_edge = layer.linear_3.weight
+        w_nodes, w_edge = layer.fused_linear.weight, layer.linear_3.weight
     elif isinstance(layer, MPNNLayerCat):
         f = layer.in_channels
         w = layer.linear.weight
-        ab = dense.project(x_local, torch.cat([w[:, :f], w[:, f:2 * f]], dim=0))
-        w_edge = w[:, 2 * f:]
+        w_nodes, w_edge = torch.cat([w[:, :f], w[:, f:2 * f]], dim=0), w[:, 2 * f:]
     else:
         raise TypeError(f"unsupported layer type {type(layer).__name__}")
+    w_out = layer.linear_out.weight
+    if (aggregate_fn is None and pg.world > 1 and x_local.dtype == torch.float32
+            and layer_fn.supported(x_local, edge_attr_local, w_nodes, w_edge, w_out)):
+        # the whole layer as one autograd node with the two exchanges inside
+        return layer_fn.layer_forward(x_local, edge_attr_local, w_nodes, w_edge, w_out, pg.graph, Halo(pg, group))
+    aggregate_fn = aggregate_fn or ops.aggregate
+    ab = dense.project(x_local, w_nodes)
     h = ab.size(1) // 2
     b_all = halo_all_gather(ab[:, h:], pg, group)
     aggr = aggregate_fn(ab[:, :h], b_all, edge_attr_local, w_edge, pg.graph)
