@@ -94,14 +94,17 @@ static float run(const float4* table, const int* idx, float4* out, long n_out, i
     return ms / 3;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool contig = argc > 1 && argv[1][0] == 'c';   // physically contiguous table (hipDeviceMallocContiguous)
     const int deg = 25;
     const long n_out = 2'000'000;   // 50 M gathers per launch
-    const long max_table_bytes = 8L << 30;
+    const long max_table_bytes = 4L << 30;
     float4* table;
     int* idx;
     float4* out;
-    CHECK(hipMalloc(&table, max_table_bytes));
+    if (contig) CHECK(hipExtMallocWithFlags((void**)&table, max_table_bytes, hipDeviceMallocContiguous));
+    else CHECK(hipMalloc(&table, max_table_bytes));
+    std::printf("table allocation: %s\n", contig ? "hipDeviceMallocContiguous" : "hipMalloc");
     CHECK(hipMemset(table, 0, max_table_bytes));
     CHECK(hipMalloc(&idx, n_out * deg * sizeof(int)));
     CHECK(hipMalloc(&out, n_out * 512));
