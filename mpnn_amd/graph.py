@@ -13,10 +13,21 @@ import torch
 
 from . import _lib
 
-# Row-splitting rule of mpnn_items_build: rows longer than CHUNK edges are cut into at most
-# MAX_PARTS pieces of at least CHUNK edges.
+# Row-splitting rule of mpnn_items_build: rows longer than `chunk` edges are cut into at most
+# MAX_PARTS pieces of at least `chunk` edges.  A piece costs a partial row written and summed again, so pieces
+# should be as long as the parallelism of the edge list allows: `chunk` grows with the number of edges
+# (the largest power of two <= E / 65536) between CHUNK and CHUNK_MAX.
 CHUNK = 64
+CHUNK_MAX = 1024
 MAX_PARTS = 256
+
+
+def default_chunk(num_edges: int) -> int:
+    """Shortest split piece for an edge list of this size (pure integer rule, mirrored by the tests)."""
+    c = CHUNK
+    while 2 * c <= CHUNK_MAX and 2 * c * 65536 <= num_edges:
+        c *= 2
+    return c
 
 
 class CSR:
@@ -77,7 +88,8 @@ def _finish(csrs, pending) -> None:
 
 
 def build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: int,
-              chunk: int = CHUNK, max_parts: int = MAX_PARTS) -> CSR:
+              chunk: int | None = None, max_parts: int = MAX_PARTS) -> CSR:
+    chunk = default_chunk(key.numel()) if chunk is None else chunk
     csr, pending = _build_csr(key, other, num_rows, num_cols, chunk, max_parts)
     _finish([csr], [pending])
     return csr
@@ -92,7 +104,7 @@ class MPGraph:
     """
 
     def __init__(self, edge_index: torch.Tensor, num_dst: int, num_src: int | None = None,
-                 chunk: int = CHUNK, max_parts: int = MAX_PARTS):
+                 chunk: int | None = None, max_parts: int = MAX_PARTS):
         _lib.require_device(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
@@ -102,6 +114,7 @@ class MPGraph:
         src = edge_index[0].contiguous()
         dst = edge_index[1].contiguous()
         self.num_dst, self.num_src, self.num_edges = int(num_dst), int(num_src), src.numel()
+        chunk = default_chunk(self.num_edges) if chunk is None else chunk
         self.by_dst, p1 = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts)
         self.by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts)
         _finish([self.by_dst, self.by_src], [p1, p2])

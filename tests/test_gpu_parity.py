@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from conftest import assert_close, load_golden
+from mpnn_amd.graph import MAX_PARTS, default_chunk
 from oracle import reference_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -58,7 +59,24 @@ def test_csr_bit_exact_random_large(dev):
     assert torch.equal(graph.by_src.rowptr.cpu(), want["rowptr_t"])
     assert torch.equal(graph.by_src.col.cpu(), want["col_t"])
     assert torch.equal(graph.by_src.eid.cpu(), want["eid_t"])
-    items, split, parts = O.work_items(want["rowptr"], 64, 256)
+    items, split, parts = O.work_items(want["rowptr"], default_chunk(int(want["rowptr"][-1])), MAX_PARTS)
+    assert torch.equal(graph.by_dst.items[:graph.by_dst.n_items].cpu(), items)
+    assert torch.equal(graph.by_dst.split[:graph.by_dst.n_split].cpu(), split)
+    assert graph.by_dst.n_parts == parts and parts > 0
+
+
+def test_work_items_of_a_large_edge_list_use_longer_pieces(dev):
+    """From 2^23 edges on the split pieces are at least 128 edges long (default_chunk); the items stay bit-exact."""
+    gen = torch.Generator().manual_seed(12)
+    n, e = 20_000, 9_000_000
+    dst = (torch.rand(e, generator=gen) ** 3 * n).long().clamp_(max=n - 1)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), dst])
+    assert default_chunk(e) == 128
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0)
+    items, split, parts = O.work_items(rowptr.int(), 128, MAX_PARTS)
+    graph = _graph({"edge_index": ei, "num_nodes": n}, dev)
+    assert torch.equal(graph.by_dst.rowptr.cpu().long(), rowptr)
     assert torch.equal(graph.by_dst.items[:graph.by_dst.n_items].cpu(), items)
     assert torch.equal(graph.by_dst.split[:graph.by_dst.n_split].cpu(), split)
     assert graph.by_dst.n_parts == parts and parts > 0

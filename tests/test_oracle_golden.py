@@ -141,3 +141,13 @@ def test_dst_range_partition_balances_edges():
         counts = [int(rowptr[b[r + 1]] - rowptr[b[r]]) for r in range(world)]
         assert sum(counts) == e
         assert max(counts) <= e / world + int((rowptr[1:] - rowptr[:-1]).max())
+
+
+def test_default_chunk_rule():
+    """Shortest split piece as a function of the edge count: 64 up to 2^23 - 1 edges, then the largest power of two
+    <= E / 65536, capped at 1024."""
+    from mpnn_amd.graph import CHUNK, CHUNK_MAX, default_chunk
+    assert (CHUNK, CHUNK_MAX) == (64, 1024)
+    for e, want in [(0, 64), (899_756, 64), (2 ** 23 - 1, 64), (2 ** 23, 128), (9_000_000, 128), (2 ** 24, 256),
+                    (2 ** 26 - 1, 512), (2 ** 26, 1024), (100_000_000, 1024), (2 ** 31 - 1, 1024)]:
+        assert default_chunk(e) == want, (e, default_chunk(e), want)

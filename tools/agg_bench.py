@@ -22,7 +22,9 @@ if order:   # experiment: edge order inside each row of the two sorted structure
     if order == "both":   # forward rows ascending in src AND transpose rows ascending in dst: sort by (src, dst) pairs
         perm = torch.argsort(ei[1], stable=True); perm = perm[torch.argsort(ei[0][perm], stable=True)]
     d["edge_index"] = ei[:, perm].contiguous(); d["edge_attr"] = d["edge_attr"][perm].contiguous()
-g = MPGraph(d["edge_index"], n)
+chunk = int(os.environ.get("AGG_CHUNK", "0"))
+g = MPGraph(d["edge_index"], n, chunk=chunk) if chunk else MPGraph(d["edge_index"], n)
+print("chunk", chunk or "default", "items", g.by_dst.n_items, "parts", g.by_dst.n_parts, "| transpose items", g.by_src.n_items, "parts", g.by_src.n_parts)
 ab = torch.randn(n, 2 * H, device=dev, requires_grad=True)
 we = torch.randn(H, 4, device=dev, requires_grad=True)
 r = torch.randn(n, H, device=dev)
