@@ -86,10 +86,11 @@ __device__ __forceinline__ float4 relu_mask4(float4 v, float4 m) {
 // [32 wr, 32 wr + 32) of the 128-row step and columns [32 MT wc, 32 MT (wc + 1)) of the block's column slice.
 // k-chunks are software-pipelined: while chunk c is multiplied out of one LDS buffer, chunk c + 1 is in
 // flight from global memory into registers and is written to the other buffer before the (single) barrier.
-// TRANS swaps the MFMA operand roles so that the accumulator holds the transpose of the output tile: a lane then
-// owns 4 consecutive output columns of one row per register quad and the epilogue moves 16 bytes per access.
-// That pays when the epilogue also reads emul and writes Y2 (three arrays); for a single output the
-// 4-byte, whole-line pattern of the plain layout is faster.
+// STAGED (the epilogue that also reads emul and writes Y2): every wave passes its accumulator tiles through a
+// private 32 x 32 patch of the LDS buffer that has just been multiplied (one extra barrier per row step) and
+// moves them to memory as whole 128-byte row segments, 16 bytes per lane - three arrays are touched there, and
+// the 4-byte whole-line pattern of the plain epilogue (or 16 bytes per lane in 32 different rows) would cost as
+// much as a separate elementwise pass.  For a single output the plain epilogue is faster.
 //
 // SPLIT computes the same float32 products on the bfloat16 matrix cores, which run 16 times the rate of the
 // float32 ones: every operand value v is written to LDS as three bfloat16 pieces v = v1 + v2 + v3 (v1 = the upper
@@ -133,7 +134,7 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&p)[3]) {
   }
 }
 
-template <int MT, int WC, bool ALIGNED, bool TRANS, bool SPLIT, bool MASKED>
+template <int MT, int WC, bool ALIGNED, bool STAGED, bool SPLIT, bool MASKED>
 __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
   static_assert(!SPLIT || ALIGNED, "the split form needs 16-byte aligned rows");
   constexpr int NTHREADS = kBlock * WC;
@@ -323,21 +324,12 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
         const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(wrow);
         const bf16x8 b2 = *reinterpret_cast<const bf16x8*>(wrow + 2 * kSplitBK);
         const bf16x8 b3 = *reinterpret_cast<const bf16x8*>(wrow + 4 * kSplitBK);
-        if (TRANS) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a3, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3, a1, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a2, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a2, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2, a1, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[t], 0, 0, 0);
-        } else {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
-        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -346,35 +338,38 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
           const float4 bv = *reinterpret_cast<const float4*>(Ws + ((wc * MT + t) * 32 + li) * ROWB + (kq * 8 + lh * 4) * 4);
-          if (TRANS) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.x, av.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.y, av.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.z, av.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv.w, av.w, acc[t], 0, 0, 0);
-          } else {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
-          }
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc[t], 0, 0, 0);
         }
       }
     }
-    if (last_chunk && TRANS) {
-      // Transposed tile: output row = lane & 31, column within the 32-wide tile = (reg & 3) + 8 * (reg >> 2)
-      // + 4 * (lane >> 5); registers 4i..4i+3 are 4 consecutive columns.  The host picks this variant only
-      // when every output row starts on a 16-byte boundary and M % 4 == 0.
-      const int64_t row = row0 + wr * 32 + li;
+    if (last_chunk && STAGED) {
+      // C layout of a 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  The
+      // buffer just multiplied is free once every wave has left the loop above; the next write into it is the
+      // stash of the following iteration, which comes after this iteration's closing barrier.  The host picks
+      // this variant only when every output row starts on a 16-byte boundary and M % 4 == 0.
+      __syncthreads();
+      constexpr int PITCH = 36;   // floats: 9 sixteen-byte slots, conflict-free 16-byte reads
+      float* patch = reinterpret_cast<float*>(ldsb + buf * STAGEB) + wid * (32 * PITCH);
+      const int prow = lane >> 3, pc4 = (lane & 7) * 4;   // a lane moves 4 columns of rows prow, prow + 8, ..
 #pragma unroll
       for (int t = 0; t < MT; ++t) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int col = m0 + (wc * MT + t) * 32 + 8 * i + 4 * lh;
-          float4 v = make_float4(acc[t][4 * i], acc[t][4 * i + 1], acc[t][4 * i + 2], acc[t][4 * i + 3]);
-          if (a.relu) {
-            v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
-            v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
-          }
+        for (int r = 0; r < 16; ++r) {
+          float v = acc[t][r];
+          if (a.relu) v = v <= 0.f ? 0.f : v;
+          patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + li] = v;
+          acc[t][r] = 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int col = m0 + (wc * MT + t) * 32 + pc4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int pr = prow + 8 * k;
+          const int64_t row = row0 + wr * 32 + pr;
+          const float4 v = *reinterpret_cast<const float4*>(patch + pr * PITCH + pc4);
           if (row < a.N && col < a.M) {
             *reinterpret_cast<float4*>(a.Y + row * a.ldy + col) = v;
             if (a.Y2) {
@@ -383,14 +378,13 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
             }
           }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        __builtin_amdgcn_wave_barrier();
       }
       ++step;
       c = 0;
     } else if (last_chunk) {
       // C layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-      constexpr bool WITH_Y2 = !SPLIT;   // the split form leaves a second output to the transposed variant
+      constexpr bool WITH_Y2 = !SPLIT;   // the split form leaves a second output to the staged variant
       const bool interior = row0 + kBN <= a.N && m0 + WROWS <= a.M;   // uniform over the block
       if (interior && !(WITH_Y2 && a.Y2)) {
         // whole tile inside the matrix: one running row pointer, the MT column tiles at immediate offsets
@@ -863,19 +857,27 @@ static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
   if (blocks > 1024) blocks = 1024;
   constexpr int WROWS = 32 * MT * WC;
   dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
-  // transposed accumulator tile only for the three-array epilogue, and only when 16-byte accesses are legal
-  const bool trans = a.Y2 && (a.M & 3) == 0 && ((a.ldy | a.ldy2 | a.ldemul) & 3) == 0 &&
-                     (((uintptr_t)a.Y | (uintptr_t)a.Y2 | (uintptr_t)a.emul) & 15) == 0;
+  // LDS-staged epilogue only for the three-array case, and only when 16-byte accesses are legal
+  const bool staged = a.Y2 && (a.M & 3) == 0 && ((a.ldy | a.ldy2 | a.ldemul) & 3) == 0 &&
+                      (((uintptr_t)a.Y | (uintptr_t)a.Y2 | (uintptr_t)a.emul) & 15) == 0;
   const bool has_mask = a.seg[0].mask || (a.nseg > 1 && a.seg[1].mask);
   auto go = [&](auto kern, size_t lds) { kern<<<grid, kBlock * WC, lds, stream>>>(a); };
-  if (aligned && gemm_split() && (trans || !a.Y2)) {
-    const size_t lds = (size_t)2 * (kBN + WROWS) * kSplitRowB;
-    if (trans) has_mask ? go(k_gemm_nt<MT, WC, true, true, true, true>, lds) : go(k_gemm_nt<MT, WC, true, true, true, false>, lds);
-    else has_mask ? go(k_gemm_nt<MT, WC, true, false, true, true>, lds) : go(k_gemm_nt<MT, WC, true, false, true, false>, lds);
+  constexpr size_t kPatches = (size_t)4 * WC * 32 * 36 * sizeof(float);   // one 32 x 32 patch (pitch 36) per wave
+  constexpr size_t lds_split = (size_t)2 * (kBN + WROWS) * kSplitRowB;
+  constexpr bool split_can_stage = (kBN + WROWS) * kSplitRowB >= kPatches;   // not the narrowest tile (MT = 1)
+  if (aligned && gemm_split() && !a.Y2) {
+    has_mask ? go(k_gemm_nt<MT, WC, true, false, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, false, true, false>, lds_split);
     return;
   }
+  if constexpr (split_can_stage) {
+    if (aligned && gemm_split() && staged) {
+      has_mask ? go(k_gemm_nt<MT, WC, true, true, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, true, true, false>, lds_split);
+      return;
+    }
+  }
   const size_t lds = (size_t)2 * (kBN + WROWS) * kLd * sizeof(float);
-  if (trans) {
+  static_assert((kBN + WROWS) * kLd * sizeof(float) >= kPatches, "the staged epilogue needs one LDS buffer for its patches");
+  if (staged) {
     if (aligned) go(k_gemm_nt<MT, WC, true, true, false, true>, lds);
     else go(k_gemm_nt<MT, WC, false, true, false, true>, lds);
   } else if (has_mask) {

@@ -159,7 +159,57 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt_bf16(NtBf16Args a) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[t], 0, 0, 0);
       }
     }
-    if (last_chunk) {
+    if (last_chunk && a.Y2) {
+      // Three arrays are touched (Y, emul, Y2): the tiles go through a wave-private patch of the LDS buffer that
+      // has just been multiplied (free once every wave has left the loop above; its next writer is the stash of
+      // the following iteration, behind this iteration's closing barrier) and leave as whole row segments,
+      // 8 columns per lane.  TPB tiles share a patch when the buffer is large enough.
+      __syncthreads();
+      constexpr int TPB = (MT == 4 && WC == 1) ? 2 : 1;
+      constexpr int PITCH = 32 * TPB + 4;                 // floats; 16-byte slots per row odd
+      static_assert((size_t)STAGEB >= (size_t)4 * WC * 32 * PITCH * sizeof(float), "patches must fit one LDS buffer");
+      constexpr int LPRW = 4 * TPB, RPP = 64 / LPRW;      // lanes per patch row, rows per pass
+      float* patch = reinterpret_cast<float*>(ldsb + st * STAGEB) + wid * (32 * PITCH);
+      const int prow = lane / LPRW, pc8 = (lane % LPRW) * 8;
+#pragma unroll
+      for (int tb = 0; tb < MT; tb += TPB) {
+#pragma unroll
+        for (int tt = 0; tt < TPB; ++tt) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {   // transposed tile: row = lane & 31, columns 8 i + 4 (lane >> 5) .. + 3
+            float4 v = make_float4(acc[tb + tt][4 * i], acc[tb + tt][4 * i + 1], acc[tb + tt][4 * i + 2], acc[tb + tt][4 * i + 3]);
+            if (a.relu) {
+              v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
+              v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
+            }
+            *reinterpret_cast<float4*>(patch + li * PITCH + tt * 32 + 8 * i + 4 * lh) = v;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tb + tt][r] = 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int col = m0 + (wc * MT + tb) * 32 + pc8;
+#pragma unroll
+        for (int k = 0; k < 32 / RPP; ++k) {
+          const int pr = prow + RPP * k;
+          const int64_t row = row0 + wr * 32 + pr;
+          const float4 v0 = *reinterpret_cast<const float4*>(patch + pr * PITCH + pc8);
+          const float4 v1 = *reinterpret_cast<const float4*>(patch + pr * PITCH + pc8 + 4);
+          if (row < a.N && col < a.M) {   // M is a multiple of 8: a lane's 8 columns are inside or outside
+            *reinterpret_cast<uint4*>(a.Y + row * a.ldy + col) =
+                make_uint4(pack2_bf16(v0.x, v0.y), pack2_bf16(v0.z, v0.w), pack2_bf16(v1.x, v1.y), pack2_bf16(v1.z, v1.w));
+            const float4 e0 = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
+            const float4 e1 = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col + 4);
+            *reinterpret_cast<uint4*>(a.Y2 + row * a.ldy2 + col) =
+                make_uint4(pack2_bf16(v0.x * e0.x, v0.y * e0.y), pack2_bf16(v0.z * e0.z, v0.w * e0.w),
+                           pack2_bf16(v1.x * e1.x, v1.y * e1.y), pack2_bf16(v1.z * e1.z, v1.w * e1.w));
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      ++step;
+      c = 0;
+    } else if (last_chunk) {
       // transposed tile: output row = lane & 31, column within the 32-wide tile = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
       const int64_t row = row0 + wr * 32 + li;
 #pragma unroll
@@ -174,11 +224,6 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt_bf16(NtBf16Args a) {
           }
           if (row < a.N && col < a.M) {
             *reinterpret_cast<uint2*>(a.Y + row * a.ldy + col) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
-            if (a.Y2) {
-              const float4 e = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
-              *reinterpret_cast<uint2*>(a.Y2 + row * a.ldy2 + col) =
-                  make_uint2(pack2_bf16(v.x * e.x, v.y * e.y), pack2_bf16(v.z * e.z, v.w * e.w));
-            }
           }
         }
 #pragma unroll
@@ -409,6 +454,8 @@ extern "C" int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W
     return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: leading dimension too small");
   if (Y2 && (!emul || ldemul < M || ldy2 < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: Y2 needs emul and ld >= M");
   const uintptr_t ptrs = (uintptr_t)X1 | (uintptr_t)W1 | (uintptr_t)X2 | (uintptr_t)W2 | (uintptr_t)emul;
+  if (Y2 && ((((uintptr_t)Y | (uintptr_t)Y2) & 15) || ((ldy | ldy2) & 7)))
+    return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: with Y2, Y and Y2 must be 16-byte aligned with row strides that are multiples of 8");
   if ((ptrs & 15) || (((uintptr_t)Y | (uintptr_t)Y2) & 7) || ((ldx1 | ldw1 | ldx2 | ldw2) & 7) || ((ldy | ldy2 | ldemul) & 3))
     return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: operands must be 16-byte aligned with row strides that keep them so");
   NtBf16Args a;
