@@ -1,7 +1,7 @@
 """Benchmark of the MPNN layer hot path: edges/sec for one layer forward+backward.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload powerlaw|flickr|modelnet|qm9]
-                  [--mode sum|cat] [--dtype f32|bf16] [--no-cpu-baseline]
+                  [--mode sum|cat] [--layer mpnn|egnn] [--dtype f32|bf16] [--no-cpu-baseline]
 
 A step is one full forward + backward of one MPNN layer (node GEMMs, fused gather/message/
 aggregate pass, update GEMM, and every gradient: x, all weights) on a synthetic graph whose
@@ -69,6 +69,12 @@ def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0):
                         mask-bit form,    per edge: col_t, tpos, mask words, G[dst] row, edge_attr
                         per row:  item record, (B row,) gB row
     """
+    if kind == "egnn_fwd":         # per edge: col, B[src] row, edge_attr, pos[src]; per row: item, A, out, pos in/out
+        return e * (4 + h * s + fe * s + 12) + n_rows * (16 + 2 * h * s + 24)
+    if kind == "egnn_bwd_dst":     # the forward's reads again + per row: upstream gradient row and g pos in, gA and S out
+        return e * (4 + h * s + fe * s + 12) + n_rows * (16 + 3 * h * s + 40)
+    if kind == "egnn_bwd_src":     # per edge: col_t, A[dst] and G[dst] rows, edge_attr, pos[dst], g pos[dst]
+        return e * (4 + 2 * h * s + fe * s + 24) + n_rows * (16 + 2 * h * s + 24)
     if kind == "aggregate_fwd":
         return e * (4 + h * s + fe * s + 4 * mask_words) + n_rows * (16 + 2 * h * s + 4 * h)
     if kind == "aggregate_bwd_src":
@@ -150,6 +156,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="powerlaw", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="sum", choices=["sum", "cat"])
+    ap.add_argument("--layer", default="mpnn", choices=["mpnn", "egnn"],
+                    help="egnn: EGNNLayer (message pass + coordinate update in one edge pass; single GPU)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -193,7 +201,15 @@ def main():
     n_total, e_total = d["num_nodes"], d["edge_index"].size(1)
     F_in, H, Fe = d["x"].size(1), cfg["H"], d["edge_attr"].size(1)
     torch.manual_seed(0)
-    layer = (MPNNLayerSum if args.mode == "sum" else MPNNLayerCat)(F_in, Fe, H).to(dev, dtype)
+    if args.layer == "egnn":
+        if world > 1:
+            raise SystemExit("--layer egnn runs on one GPU (batched workloads scale by data parallelism)")
+        from mpnn_amd import EGNNLayer
+        layer = EGNNLayer(F_in, Fe, H).to(dev, dtype)
+        pos = d["pos"].float() if "pos" in d else torch.randn(n_total, 3, device=dev)
+        pos = pos.clone().requires_grad_(True)
+    else:
+        layer = (MPNNLayerSum if args.mode == "sum" else MPNNLayerCat)(F_in, Fe, H).to(dev, dtype)
 
     if world == 1:
         x = d["x"].to(dtype).requires_grad_(not args.first_layer)
@@ -210,7 +226,7 @@ def main():
         torch.cuda.synchronize()
         graph_build_ms = (time.perf_counter() - tb) / 5 * 1e3
         n_rows_fwd, n_rows_bwd, e_local = n_total, n_total, e_total
-        forward = lambda: layer(x, ei, ea)
+        forward = (lambda: layer(x, pos, ei, ea)) if args.layer == "egnn" else (lambda: layer(x, ei, ea))
     else:
         graph_build_ms = None
         pg = PartitionedGraph(d["edge_index"], n_total, rank, world)
@@ -223,13 +239,18 @@ def main():
     note("graph structures built; warming up")
     gen = torch.Generator(device=dev).manual_seed(2)
     r = torch.randn(x.size(0), H, generator=gen, device=dev).to(dtype)
+    rp = torch.randn(x.size(0), 3, generator=gen, device=dev) if args.layer == "egnn" else None
 
     def step():
         for p in layer.parameters():
             p.grad = None
         x.grad = None
         out = forward()
-        out.backward(r)          # dense upstream gradient, as a following layer would supply
+        if args.layer == "egnn":
+            pos.grad = None
+            torch.autograd.backward(list(out), [r, rp])   # dense upstream gradients for features and coordinates
+        else:
+            out.backward(r)      # dense upstream gradient, as a following layer would supply
         if world > 1:
             allreduce_gradients(layer)
 
@@ -286,7 +307,8 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        rows = {"aggregate_fwd": n_rows_fwd, "aggregate_bwd_src": n_rows_bwd}
+        rows = {"aggregate_fwd": n_rows_fwd, "aggregate_bwd_src": n_rows_bwd, "egnn_fwd": n_rows_fwd,
+                "egnn_bwd_dst": n_rows_fwd, "egnn_bwd_src": n_rows_bwd}
         per_kernel = {}
         from mpnn_amd import _lib
         mask_words = _lib.load().mpnn_mask_words(H, _lib.dtype_code(dtype)) if ops.USE_MASKBITS else 0
@@ -306,7 +328,8 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {cfg['desc']}" + (f" (scale {args.scale})" if args.scale != 1 else ""),
-                       "layer": f"MPNNLayer{args.mode.capitalize()}" + (" (first layer: no input gradient)" if args.first_layer else ""),
+                       "layer": ("EGNNLayer" if args.layer == "egnn" else f"MPNNLayer{args.mode.capitalize()}")
+                                + (" (first layer: no input gradient)" if args.first_layer else ""),
                        "num_nodes": n_total, "num_edges": e_total,
                        "in_features": F_in, "hidden": H, "edge_features": Fe,
                        "parallelism": "single GPU" if world == 1 else f"dst-range partition x{world} + halo all-gather",
@@ -314,7 +337,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.workload, args.dtype, dom) if (world == 1 and args.scale == 1.0
-                                                                                     and args.mode == "sum") else None},
+                                                                                     and args.mode == "sum"
+                                                                                     and args.layer == "mpnn") else None},
             "kernels": per_kernel,
             "message_passing_only": {
                 "ms": mp_time * 1e3, "edges_per_sec": e_local / mp_time,
@@ -327,7 +351,7 @@ def main():
                 "note": "dst-sorted CSR + src-sorted transpose + work items from edge_index; paid once for a static "
                         "graph, once per mini-batch for batched workloads",
                 "edges_per_sec_if_rebuilt_every_step": e_total / (elapsed / args.steps + graph_build_ms * 1e-3)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.layer == "mpnn":
             result["cpu_baseline"] = cpu_baseline(args.workload, args.mode)
         print(json.dumps(result), flush=True)
     if world > 1:
