@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 4
+#define MPNN_ABI_VERSION 5
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -313,6 +313,8 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
  *   float32 matrix-core instructions, which unaligned operands (K % 4 != 0) always take.
  * mpnn_gemm_tn_f32:  dW[M,K] = (G * (mask > 0))[N,M]^T X[N,K]  (weight gradient; rows are summed in a fixed
  *   order through `scratch`, float, at least mpnn_gemm_tn_scratch_floats(N, M, K) elements).
+ *   X2 (optional, [N,K2], K2 = 0 without it): dW[M, K+K2] = (G * (mask > 0))^T [X | X2] in one pass over G
+ *   (the gradient of linear_out over its two inputs x and aggr); scratch is sized with K + K2.
  *   Gout (optional, [N,M], needs 16-byte aligned operands): G * (mask > 0) is also written out, so that the
  *   other GEMMs of the backward read one matrix instead of two.  Runs on the float32 matrix-core instructions.
  * All matrices row-major with leading dimensions in elements.
@@ -324,8 +326,9 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
                          int64_t ldy2, int64_t N, int32_t M, int32_t relu, mpnn_stream_t stream);
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K);
 int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm,
-                         const float* X, int64_t ldx, float* dW, int64_t lddw, float* scratch,
-                         float* Gout, int64_t ldgo, int64_t N, int32_t M, int32_t K, mpnn_stream_t stream);
+                         const float* X, int64_t ldx, const float* X2, int64_t ldx2, float* dW,
+                         int64_t lddw, float* scratch, float* Gout, int64_t ldgo, int64_t N, int32_t M,
+                         int32_t K, int32_t K2, mpnn_stream_t stream);
 
 /* bfloat16 form of mpnn_gemm_nt_f32 for bfloat16 models (bf16 storage, float32 accumulation, no operand mask):
  *   Y[N,M] = act( X1 W1^T + X2 W2^T ),  optionally  Y2 = Y * emul  with emul float32 [N,M].

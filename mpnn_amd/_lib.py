@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -90,7 +90,8 @@ SIGNATURES = {
                                     c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_gemm_tn_scratch_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "mpnn_gemm_tn_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                   c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
+                                   c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+                                   c_void_p]),
     "mpnn_gemm_tn_bf16_scratch_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "mpnn_gemm_tn_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),

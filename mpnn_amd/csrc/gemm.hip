@@ -454,10 +454,25 @@ struct TnArgs {
   const float* G; int64_t ldg;        // [N, M]
   const float* mask; int64_t ldm;     // optional [N, M]: G is used where mask > 0
   const float* X; int64_t ldx;        // [N, K]
+  const float* X2; int64_t ldx2;      // optional [N, K2]: dW = G^T [X | X2], the column tiles of X2 follow those of X
   float* gout; int64_t ldgo;          // optional [N, M]: G * (mask > 0), written by the blocks of the first K tile
-  float* partial;                     // [gridDim.x][M][K]
-  int64_t N; int M; int K;
+  float* partial;                     // [gridDim.x][M][K + K2]
+  int64_t N; int M; int K; int K2;
 };
+
+// The right-hand matrix a block's column tile (blockIdx.z) lies in, the tile's first column inside it, and the
+// tile's first column in dW.
+struct TnTile {
+  const float* X; int64_t ldx; int K; int k0; int kout0;
+};
+__device__ __forceinline__ TnTile tn_tile(const TnArgs& a) {
+  const int z1 = (a.K + 127) / 128;
+  if (a.X2 && (int)blockIdx.z >= z1) {
+    const int k0 = ((int)blockIdx.z - z1) * 128;
+    return TnTile{a.X2, a.ldx2, a.K2, k0, a.K + k0};
+  }
+  return TnTile{a.X, a.ldx, a.K, (int)blockIdx.z * 128, (int)blockIdx.z * 128};
+}
 
 #ifndef MPNN_TN_DEPTH
 #define MPNN_TN_DEPTH 2
@@ -491,7 +506,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
   const int wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
-  const int m0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+  const TnTile xt = tn_tile(a);
+  const int m0 = blockIdx.y * 128, k0 = xt.k0;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -512,14 +528,14 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
       const int64_t rbase = n0 < a.N ? n0 : a.N - 1;
       const float* gb = a.G + rbase * a.ldg;
       const float* mb = MASKED ? a.mask + rbase * a.ldm : nullptr;
-      const float* xb = a.X + rbase * a.ldx;
-      const uint32_t gc = m0 + pc < a.M ? m0 + pc : a.M - 4, xc = k0 + pc < a.K ? k0 + pc : a.K - 4;
+      const float* xb = xt.X + rbase * xt.ldx;
+      const uint32_t gc = m0 + pc < a.M ? m0 + pc : a.M - 4, xc = k0 + pc < xt.K ? k0 + pc : xt.K - 4;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t r = pr + 8 * q < rt_max ? pr + 8 * q : rt_max;
         gr[st][q] = *reinterpret_cast<const float4*>(gb + (r * (uint32_t)a.ldg + gc));
         if constexpr (MASKED) mr[st][q] = *reinterpret_cast<const float4*>(mb + (r * (uint32_t)a.ldm + gc));
-        xr[st][q] = *reinterpret_cast<const float4*>(xb + (r * (uint32_t)a.ldx + xc));
+        xr[st][q] = *reinterpret_cast<const float4*>(xb + (r * (uint32_t)xt.ldx + xc));
       }
     } else {
 #pragma unroll
@@ -528,7 +544,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
         row = row < a.N ? row : a.N - 1;
         gr[st][q] = load_chunk4<ALIGNED>(a.G + row * a.ldg, m0 + pc, a.M);
         if constexpr (MASKED) mr[st][q] = load_chunk4<ALIGNED>(a.mask + row * a.ldm, m0 + pc, a.M);
-        xr[st][q] = load_chunk4<ALIGNED>(a.X + row * a.ldx, k0 + pc, a.K);
+        xr[st][q] = load_chunk4<ALIGNED>(xt.X + row * xt.ldx, k0 + pc, xt.K);
       }
     }
   };
@@ -545,7 +561,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
         if (row_ok && m0 + pc < a.M) *reinterpret_cast<float4*>(a.gout + (nslab + r) * a.ldgo + m0 + pc) = g;
       }
       *reinterpret_cast<float4*>(&Gs[buf][r][pc]) = g;
-      *reinterpret_cast<float4*>(&Xs[buf][r][pc]) = select4(xr[st][q], valid4(k0 + pc, a.K, row_ok));
+      *reinterpret_cast<float4*>(&Xs[buf][r][pc]) = select4(xr[st][q], valid4(k0 + pc, xt.K, row_ok));
     }
   };
   auto multiply = [&](int buf) {
@@ -619,16 +635,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
         if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
     }
   }
-  float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
+  const int ktot = a.K + a.K2;
+  float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = k0 + wk + j * 32 + li;
+      const int cl = k0 + wk + j * 32 + li;   // column inside the tile's matrix
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < a.M && col < a.K) out[(int64_t)row * a.K + col] = acc[i][j][r];
+        if (row < a.M && cl < xt.K) out[(int64_t)row * ktot + (xt.kout0 - k0) + cl] = acc[i][j][r];
       }
     }
 }
@@ -663,7 +680,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
   const int wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
-  const int m0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+  const TnTile xt = tn_tile(a);
+  const int m0 = blockIdx.y * 128, k0 = xt.k0;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -675,8 +693,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
 
   // a thread moves 2 float4 per matrix and slab: rows tid/32 + 8 q, columns 4 (tid % 32) ..
   const int pr = tid >> 5, pc = (tid & 31) * 4;
-  const bool cols_full = m0 + 128 <= a.M && k0 + 128 <= a.K;
-  const uint32_t gc = m0 + pc < a.M ? m0 + pc : a.M - 4, xc = k0 + pc < a.K ? k0 + pc : a.K - 4;
+  const bool cols_full = m0 + 128 <= a.M && k0 + 128 <= xt.K;
+  const uint32_t gc = m0 + pc < a.M ? m0 + pc : a.M - 4, xc = k0 + pc < xt.K ? k0 + pc : xt.K - 4;
   float4 gr[D][2], mr[MASKED ? D : 1][2], xr[D][2];
   auto fetch = [&](auto S, int64_t n0) {   // scalar slab base + 32-bit lane offsets
     constexpr int st = decltype(S)::value;
@@ -685,13 +703,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
     const int64_t rbase = n0 < a.N ? n0 : a.N - 1;
     const float* gb = a.G + rbase * a.ldg;
     const float* mb = MASKED ? a.mask + rbase * a.ldm : nullptr;
-    const float* xb = a.X + rbase * a.ldx;
+    const float* xb = xt.X + rbase * xt.ldx;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const uint32_t r = pr + 8 * q < rt_max ? pr + 8 * q : rt_max;
       gr[st][q] = *reinterpret_cast<const float4*>(gb + (r * (uint32_t)a.ldg + gc));
       if constexpr (MASKED) mr[st][q] = *reinterpret_cast<const float4*>(mb + (r * (uint32_t)a.ldm + gc));
-      xr[st][q] = *reinterpret_cast<const float4*>(xb + (r * (uint32_t)a.ldx + xc));
+      xr[st][q] = *reinterpret_cast<const float4*>(xb + (r * (uint32_t)xt.ldx + xc));
     }
   };
   auto stash = [&](auto S, int buf, int64_t nslab) {
@@ -706,7 +724,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
       if (!full) {   // rows and columns past the end must contribute exact zeros to the sums
         const bool row_ok = nslab + r < a.N;
         g = select4(g, valid4(m0 + pc, a.M, row_ok));
-        x = select4(x, valid4(k0 + pc, a.K, row_ok));
+        x = select4(x, valid4(k0 + pc, xt.K, row_ok));
       }
       if constexpr (MASKED) g = relu_mask4(g, mr[st][q]);
       if (emit && nslab + r < a.N && m0 + pc < a.M)   // the masked gradient, one whole 512-byte row per 32 lanes
@@ -779,16 +797,17 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
         if (it + 3 < total) body(std::integral_constant<int, 3>{}, it + 3);
     }
   }
-  float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
+  const int ktot = a.K + a.K2;
+  float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = k0 + wk + j * 32 + li;
+      const int cl = k0 + wk + j * 32 + li;   // column inside the tile's matrix
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < a.M && col < a.K) out[(int64_t)row * a.K + col] = acc[i][j][r];
+        if (row < a.M && cl < xt.K) out[(int64_t)row * ktot + (xt.kout0 - k0) + cl] = acc[i][j][r];
       }
     }
 }
@@ -921,39 +940,43 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
   return MPNN_OK;
 }
 
-int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K) {
+int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K) {   // K = K + K2 of the call
   if (N < 0 || M < 1 || K < 1) return -1;
-  return (int64_t)tn_slabs(N, M, K) * M * K;
+  return (int64_t)tn_slabs(N, M, K) * M * K;   // two matrices make one tile more at most: fewer slabs, never more
 }
 
 int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm, const float* X, int64_t ldx,
-                         float* dW, int64_t lddw, float* scratch, float* Gout, int64_t ldgo, int64_t N, int32_t M,
-                         int32_t K, mpnn_stream_t stream) {
-  if (N < 0 || M < 1 || K < 1) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: bad sizes");
+                         const float* X2, int64_t ldx2, float* dW, int64_t lddw, float* scratch, float* Gout,
+                         int64_t ldgo, int64_t N, int32_t M, int32_t K, int32_t K2, mpnn_stream_t stream) {
+  if (N < 0 || M < 1 || K < 1 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: bad sizes");
   if (!dW) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: dW is null");
-  if (lddw < K) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: lddw below K");
+  const int ktot = K + K2;
+  if (lddw < ktot) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: lddw below K + K2");
   if (N == 0) {
-    MPNN_HIP_CHECK(hipMemset2DAsync(dW, (size_t)lddw * 4, 0, (size_t)K * 4, (size_t)M, stream));
+    MPNN_HIP_CHECK(hipMemset2DAsync(dW, (size_t)lddw * 4, 0, (size_t)ktot * 4, (size_t)M, stream));
     return MPNN_OK;
   }
-  if (!G || !X || !scratch) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: null pointer argument");
-  if (ldg < M || ldx < K || (mask && ldm < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: leading dimension too small");
-  TnArgs a{G, ldg, mask, ldm, X, ldx, Gout, ldgo, scratch, N, M, K};
-  const int slabs = tn_slabs(N, M, K);
+  if (!G || !X || !scratch || (K2 > 0 && !X2)) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: null pointer argument");
+  if (ldg < M || ldx < K || (mask && ldm < M) || (K2 > 0 && ldx2 < K2))
+    return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: leading dimension too small");
+  TnArgs a{G, ldg, mask, ldm, X, ldx, K2 > 0 ? X2 : nullptr, ldx2, Gout, ldgo, scratch, N, M, K, K2};
+  const int ztiles = (K + 127) / 128 + (K2 + 127) / 128;
+  const int slabs = tn_slabs(N, M, ztiles * 128);
   const bool aligned = !(((uintptr_t)G & 15) || ((uintptr_t)X & 15) || (ldg & 3) || (ldx & 3) || (M & 3) || (K & 3) ||
-                         (mask && (((uintptr_t)mask & 15) || (ldm & 3))));
+                         (mask && (((uintptr_t)mask & 15) || (ldm & 3))) ||
+                         (K2 > 0 && (((uintptr_t)X2 & 15) || (ldx2 & 3) || (K2 & 3))));
   if (Gout && (!aligned || ldgo < M || ((uintptr_t)Gout & 15) || (ldgo & 3)))
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: Gout needs 16-byte aligned operands and ldgo >= M");
-  dim3 grid(slabs, (M + 127) / 128, (K + 127) / 128);
+  dim3 grid(slabs, (M + 127) / 128, ztiles);
   auto go = [&](auto kern) { kern<<<grid, kBlock, 0, stream>>>(a); };
   if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true>) : go(k_gemm_tn_tr<false>);
   else if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true>) : go(k_gemm_tn<true, true, false>);
   else if (aligned) mask ? go(k_gemm_tn<true, false, true>) : go(k_gemm_tn<true, false, false>);
   else mask ? go(k_gemm_tn<false, false, true>) : go(k_gemm_tn<false, false, false>);
   MPNN_LAUNCH_CHECK("k_gemm_tn");
-  int64_t blocks = ((int64_t)M * K + 63) / 64;
+  int64_t blocks = ((int64_t)M * ktot + 63) / 64;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-  k_sum_partials<<<(int)blocks, kBlock, 0, stream>>>(scratch, slabs, M, K, dW, lddw);
+  k_sum_partials<<<(int)blocks, kBlock, 0, stream>>>(scratch, slabs, M, ktot, dW, lddw);
   MPNN_LAUNCH_CHECK("k_sum_partials");
   return MPNN_OK;
 }

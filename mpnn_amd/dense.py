@@ -102,22 +102,24 @@ def gemm_tn_bf16(g, x, mask=None, out=None, g_out=None) -> torch.Tensor:
     return out
 
 
-def gemm_tn(g, x, mask=None, out=None, g_out=None) -> torch.Tensor:
-    """(g * (mask > 0))^T @ x  ->  [M, K]; ``out`` may be a column slice of a wider weight gradient.
+def gemm_tn(g, x, mask=None, out=None, g_out=None, x2=None) -> torch.Tensor:
+    """(g * (mask > 0))^T @ [x | x2]  ->  [M, K (+ K2)]; ``out`` may be a column slice of a wider weight gradient.
     ``g_out`` ([N, M]) receives g * (mask > 0)."""
     lib = _lib.load()
     g, x = _rows(g), _rows(x)
+    x2 = _rows(x2) if x2 is not None else None
     n, m = g.shape
     k = x.size(1)
+    k2 = x2.size(1) if x2 is not None else 0
     if out is None:
-        out = torch.empty((m, k), dtype=torch.float32, device=g.device)
+        out = torch.empty((m, k + k2), dtype=torch.float32, device=g.device)
     mask = _rows(mask) if mask is not None else None
-    scratch = _scratch(lib.mpnn_gemm_tn_scratch_floats(n, m, k), g.device)
+    scratch = _scratch(lib.mpnn_gemm_tn_scratch_floats(n, m, k + k2), g.device)
     _lib.check(lib.mpnn_gemm_tn_f32(
         _lib.ptr(g), g.stride(0), _lib.ptr(mask), mask.stride(0) if mask is not None else 0, _lib.ptr(x),
-        x.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(scratch), _lib.ptr(g_out),
-        g_out.stride(0) if g_out is not None else 0, n, m, k, _lib.stream_handle(g.device)),
-        "mpnn_gemm_tn_f32")
+        x.stride(0), _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(out), out.stride(0),
+        _lib.ptr(scratch), _lib.ptr(g_out), g_out.stride(0) if g_out is not None else 0, n, m, k, k2,
+        _lib.stream_handle(g.device)), "mpnn_gemm_tn_f32")
     return out
 
 
@@ -158,8 +160,7 @@ class _Update(torch.autograd.Function):
                 ga = gemm_nt(gy, wt[f:], mask1=y)
         if ctx.needs_input_grad[2]:
             gw = torch.empty_like(w_out)
-            gemm_tn(gy, x, mask=y, out=gw[:, :f])
-            gemm_tn(gy, aggr, mask=y, out=gw[:, f:])
+            gemm_tn(gy, x, mask=y, out=gw, x2=aggr)
         return gx, ga, gw
 
 

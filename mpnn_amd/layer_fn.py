@@ -60,12 +60,12 @@ class _LayerFn(torch.autograd.Function):
         g, m = gy, y
         # gz = gy * [y > 0] leaves the first weight-gradient GEMM as a by-product (written in whole 512-byte rows),
         # so the four GEMMs after it read one matrix instead of (gy, y); needs 16-byte aligned rows
-        if g_wout is not None and h % 4 == 0 and f % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, y, x)):
+        if g_wout is not None and h % 4 == 0 and f % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, y, x, aggr)):
             gz = torch.empty_like(gy)
-            gemm_tn(gy, x, mask=y, out=g_wout[:, :f], g_out=gz)
+            gemm_tn(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)   # both halves of gW_out in one pass over gy
             g, m = gz, None
         elif g_wout is not None:
-            gemm_tn(gy, x, mask=y, out=g_wout[:, :f])
+            gemm_tn(gy, x, mask=y, out=g_wout, x2=aggr)
         ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt, out2=g_ab[:, :h])
         if halo is None:
             g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
@@ -77,8 +77,6 @@ class _LayerFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = gemm_nt(g, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=m)
         g_wn = gemm_tn(g_ab, x) if ctx.needs_input_grad[2] else None
-        if g_wout is not None:
-            gemm_tn(g, aggr, mask=m, out=g_wout[:, f:])
         return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None, None
 
 

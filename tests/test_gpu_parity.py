@@ -380,6 +380,22 @@ def test_gemm_tn(n, m, k, dev):
     assert torch.equal(again, got.contiguous()), "weight gradient is not bitwise reproducible"
 
 
+@pytest.mark.parametrize("n,m,k,k2", [(5000, 128, 128, 128), (3001, 64, 500, 64), (700, 16, 11, 16), (2048, 256, 132, 4)])
+def test_gemm_tn_two_right_hand_matrices(n, m, k, k2, dev):
+    """dW = (g * [mask > 0])^T [x | x2] in one pass against float64 and against the two separate products (which
+    may sum their row slabs in another grouping, hence not bit for bit)."""
+    from mpnn_amd.dense import gemm_tn
+    gen = torch.Generator().manual_seed(n + k2)
+    g, mask = torch.randn(n, m, generator=gen).to(dev), torch.randn(n, m, generator=gen).to(dev)
+    x, x2 = torch.randn(n, k, generator=gen).to(dev), torch.randn(n, k2, generator=gen).to(dev)
+    both = gemm_tn(g, x, mask=mask, x2=x2)
+    want = (g.double().cpu() * (mask.cpu() > 0)).t() @ torch.cat([x, x2], 1).double().cpu()
+    assert_close(both, want, RTOL32, what="gemm_tn two matrices")
+    assert_close(both[:, :k], gemm_tn(g, x, mask=mask).double().cpu(), RTOL32, what="left part")
+    assert_close(both[:, k:], gemm_tn(g, x2, mask=mask).double().cpu(), RTOL32, what="right part")
+    assert torch.equal(both, gemm_tn(g, x, mask=mask, x2=x2)), "not reproducible"
+
+
 def test_recomputing_backward_matches_mask_bit_backward(dev):
     """The two backward forms (stored relu mask bits vs. recomputed pre-activation) give the same gradients bit for bit."""
     from mpnn_amd import ops
