@@ -340,12 +340,13 @@ int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W1, int64_t 
                           int32_t M, int32_t relu, mpnn_stream_t stream);
 /* bfloat16 form of mpnn_gemm_tn_f32 (the weight gradients of the same Linear calls): G, mask, X, Gout and dW
  * bfloat16, float32 accumulation over the rows in a fixed order, one rounding to bfloat16 at the end.
- * `scratch`: at least mpnn_gemm_tn_bf16_scratch_floats(N, M, K) floats.  M and K multiples of 8; G, mask, X, Gout
+ * X2 / K2 as in mpnn_gemm_tn_f32.  `scratch`: at least mpnn_gemm_tn_bf16_scratch_floats(N, M, K + K2) floats.  M and K multiples of 8; G, mask, X, Gout
  * 16-byte aligned with row strides that are multiples of 8 elements. */
 int64_t mpnn_gemm_tn_bf16_scratch_floats(int64_t N, int32_t M, int32_t K);
 int32_t mpnn_gemm_tn_bf16(const void* G, int64_t ldg, const void* mask, int64_t ldm, const void* X,
-                          int64_t ldx, void* dW, int64_t lddw, float* scratch, void* Gout, int64_t ldgo,
-                          int64_t N, int32_t M, int32_t K, mpnn_stream_t stream);
+                          int64_t ldx, const void* X2, int64_t ldx2, void* dW, int64_t lddw, float* scratch,
+                          void* Gout, int64_t ldgo, int64_t N, int32_t M, int32_t K, int32_t K2,
+                          mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Segment mean over an index list: out[g, :] = (1/max(cnt_g,1)) * sum_{p in seg g} x[col[p], :]

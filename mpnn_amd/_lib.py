@@ -94,7 +94,8 @@ SIGNATURES = {
                                    c_void_p]),
     "mpnn_gemm_tn_bf16_scratch_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "mpnn_gemm_tn_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
-                                    c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_void_p]),
+                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
+                                    c_void_p]),
     "mpnn_segment_mean_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                         c_int32, c_int32, c_void_p]),
     "mpnn_segment_mean_bwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

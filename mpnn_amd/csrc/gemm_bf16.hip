@@ -286,9 +286,10 @@ struct TnBf16Args {
   const bf16_t* G; int64_t ldg;      // [N, M]
   const bf16_t* mask; int64_t ldm;   // optional [N, M]
   const bf16_t* X; int64_t ldx;      // [N, K]
+  const bf16_t* X2; int64_t ldx2;    // optional [N, K2]: dW = G^T [X | X2], the column tiles of X2 follow those of X
   bf16_t* gout; int64_t ldgo;        // optional [N, M]: G * [mask > 0], written by the blocks of the first K tile
-  float* partial;                    // [gridDim.x][M][K]
-  int64_t N; int M; int K;
+  float* partial;                    // [gridDim.x][M][K + K2]
+  int64_t N; int M; int K; int K2;
 };
 
 // Two packed bfloat16 of g where the matching entries of y are > 0 (NaN counts as > 0, like `y <= 0 ? 0 : g`).
@@ -317,7 +318,14 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
   const int wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
-  const int m0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+  // the right-hand matrix this block's column tile lies in, the tile's first column there and in dW
+  const int z1 = (a.K + 127) / 128;
+  const bool second = a.X2 && (int)blockIdx.z >= z1;
+  const bf16_t* const xm = second ? a.X2 : a.X;
+  const int64_t ldxm = second ? a.ldx2 : a.ldx;
+  const int km = second ? a.K2 : a.K;
+  const int m0 = blockIdx.y * 128, k0 = (second ? (int)blockIdx.z - z1 : (int)blockIdx.z) * 128;
+  const int kout0 = second ? a.K + k0 : k0;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -329,7 +337,7 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
 
   // a thread moves two 16-byte pieces per matrix and slab: rows tid/16 and tid/16 + 16, columns 8 (tid % 16) ..
   const int pr = tid >> 4, pc = (tid & 15) * 8;
-  const bool g_ok = m0 + pc < a.M, x_ok = k0 + pc < a.K;   // widths are multiples of 8: a piece is in or out
+  const bool g_ok = m0 + pc < a.M, x_ok = k0 + pc < km;   // widths are multiples of 8: a piece is in or out
   const int gcol = g_ok ? m0 + pc : 0, xcol = x_ok ? k0 + pc : 0;
   uint4 gr[2], mr[2], xr[2];
   bool rv[2];
@@ -341,7 +349,7 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
       row = rv[q] ? row : a.N - 1;
       gr[q] = *reinterpret_cast<const uint4*>(a.G + row * a.ldg + gcol);
       if constexpr (MASKED) mr[q] = *reinterpret_cast<const uint4*>(a.mask + row * a.ldm + gcol);
-      xr[q] = *reinterpret_cast<const uint4*>(a.X + row * a.ldx + xcol);
+      xr[q] = *reinterpret_cast<const uint4*>(xm + row * ldxm + xcol);
     }
   };
   auto stash = [&](int buf, int64_t nslab) {
@@ -390,16 +398,17 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
     if (more) stash(buf ^ 1, n0 + step);
     __syncthreads();
   }
-  float* out = a.partial + (int64_t)blockIdx.x * a.M * a.K;
+  const int ktot = a.K + a.K2;
+  float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int col = k0 + wk + j * 32 + li;
+      const int cl = k0 + wk + j * 32 + li;   // column inside the tile's matrix
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < a.M && col < a.K) out[(int64_t)row * a.K + col] = acc[i][j][r];
+        if (row < a.M && cl < km) out[(int64_t)row * ktot + (kout0 - k0) + cl] = acc[i][j][r];
       }
     }
 }
@@ -480,32 +489,36 @@ extern "C" int64_t mpnn_gemm_tn_bf16_scratch_floats(int64_t N, int32_t M, int32_
 }
 
 extern "C" int32_t mpnn_gemm_tn_bf16(const void* G, int64_t ldg, const void* mask, int64_t ldm, const void* X,
-                                     int64_t ldx, void* dW, int64_t lddw, float* scratch, void* Gout, int64_t ldgo,
-                                     int64_t N, int32_t M, int32_t K, mpnn_stream_t stream) {
-  if (N < 0 || M < 8 || K < 8) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: bad sizes");
-  if ((M | K) & 7) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: M and K must be multiples of 8");
+                                     int64_t ldx, const void* X2, int64_t ldx2, void* dW, int64_t lddw, float* scratch,
+                                     void* Gout, int64_t ldgo, int64_t N, int32_t M, int32_t K, int32_t K2,
+                                     mpnn_stream_t stream) {
+  if (N < 0 || M < 8 || K < 8 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: bad sizes");
+  if ((M | K | K2) & 7) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: M, K and K2 must be multiples of 8");
   if (!dW) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: dW is null");
-  if (lddw < K) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: lddw below K");
+  const int ktot = K + K2;
+  if (lddw < ktot) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: lddw below K + K2");
   if (N == 0) {
-    MPNN_HIP_CHECK(hipMemset2DAsync(dW, (size_t)lddw * 2, 0, (size_t)K * 2, (size_t)M, stream));
+    MPNN_HIP_CHECK(hipMemset2DAsync(dW, (size_t)lddw * 2, 0, (size_t)ktot * 2, (size_t)M, stream));
     return MPNN_OK;
   }
-  if (!G || !X || !scratch) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: null pointer argument");
-  if (ldg < M || ldx < K || (mask && ldm < M) || (Gout && ldgo < M))
+  if (!G || !X || !scratch || (K2 > 0 && !X2)) return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: null pointer argument");
+  if (ldg < M || ldx < K || (mask && ldm < M) || (Gout && ldgo < M) || (K2 > 0 && ldx2 < K2))
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: leading dimension too small");
-  const uintptr_t ptrs = (uintptr_t)G | (uintptr_t)mask | (uintptr_t)X | (uintptr_t)Gout;
-  if ((ptrs & 15) || ((ldg | ldm | ldx | ldgo) & 7))
+  if (K2 == 0) { X2 = nullptr; ldx2 = 0; }
+  const uintptr_t ptrs = (uintptr_t)G | (uintptr_t)mask | (uintptr_t)X | (uintptr_t)X2 | (uintptr_t)Gout;
+  if ((ptrs & 15) || ((ldg | ldm | ldx | ldx2 | ldgo) & 7))
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_bf16: operands must be 16-byte aligned with row strides that keep them so");
   TnBf16Args a{static_cast<const bf16_t*>(G), ldg, static_cast<const bf16_t*>(mask), ldm, static_cast<const bf16_t*>(X), ldx,
-               static_cast<bf16_t*>(Gout), ldgo, scratch, N, M, K};
-  const int slabs = tn_bf16_slabs(N, M, K);
-  dim3 grid(slabs, (M + 127) / 128, (K + 127) / 128);
+               static_cast<const bf16_t*>(X2), ldx2, static_cast<bf16_t*>(Gout), ldgo, scratch, N, M, K, K2};
+  const int ztiles = (K + 127) / 128 + (K2 + 127) / 128;
+  const int slabs = tn_bf16_slabs(N, M, ztiles * 128);
+  dim3 grid(slabs, (M + 127) / 128, ztiles);
   if (mask) k_gemm_tn_bf16<true><<<grid, kBlock, 0, stream>>>(a);
   else k_gemm_tn_bf16<false><<<grid, kBlock, 0, stream>>>(a);
   MPNN_LAUNCH_CHECK("k_gemm_tn_bf16");
-  int64_t blocks = ((int64_t)M * K + 63) / 64;
+  int64_t blocks = ((int64_t)M * ktot + 63) / 64;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-  k_sum_partials_bf16<<<(int)blocks, kBlock, 0, stream>>>(scratch, slabs, M, K, static_cast<bf16_t*>(dW), lddw);
+  k_sum_partials_bf16<<<(int)blocks, kBlock, 0, stream>>>(scratch, slabs, M, ktot, static_cast<bf16_t*>(dW), lddw);
   MPNN_LAUNCH_CHECK("k_sum_partials_bf16");
   return MPNN_OK;
 }

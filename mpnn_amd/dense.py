@@ -85,20 +85,21 @@ def gemm_nt_bf16(x1, w1, x2=None, w2=None, relu=False, emul=None, out2=None) -> 
     return y
 
 
-def gemm_tn_bf16(g, x, mask=None, out=None, g_out=None) -> torch.Tensor:
-    """bfloat16 (g * (mask > 0))^T @ x -> [M, K] with float32 accumulation; ``out`` may be a column slice of a
-    wider weight gradient, ``g_out`` ([N, M]) receives g * (mask > 0)."""
+def gemm_tn_bf16(g, x, mask=None, out=None, g_out=None, x2=None) -> torch.Tensor:
+    """bfloat16 (g * (mask > 0))^T @ [x | x2] -> [M, K (+ K2)] with float32 accumulation; ``out`` may be a column
+    slice of a wider weight gradient, ``g_out`` ([N, M]) receives g * (mask > 0)."""
     lib = _lib.load()
     n, m = g.shape
     k = x.size(1)
+    k2 = x2.size(1) if x2 is not None else 0
     if out is None:
-        out = torch.empty((m, k), dtype=torch.bfloat16, device=g.device)
-    scratch = _scratch(lib.mpnn_gemm_tn_bf16_scratch_floats(n, m, k), g.device)
+        out = torch.empty((m, k + k2), dtype=torch.bfloat16, device=g.device)
+    scratch = _scratch(lib.mpnn_gemm_tn_bf16_scratch_floats(n, m, k + k2), g.device)
     _lib.check(lib.mpnn_gemm_tn_bf16(
         _lib.ptr(g), g.stride(0), _lib.ptr(mask), mask.stride(0) if mask is not None else 0, _lib.ptr(x),
-        x.stride(0), _lib.ptr(out), out.stride(0), _lib.ptr(scratch), _lib.ptr(g_out),
-        g_out.stride(0) if g_out is not None else 0, n, m, k, _lib.stream_handle(g.device)),
-        "mpnn_gemm_tn_bf16")
+        x.stride(0), _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(out), out.stride(0),
+        _lib.ptr(scratch), _lib.ptr(g_out), g_out.stride(0) if g_out is not None else 0, n, m, k, k2,
+        _lib.stream_handle(g.device)), "mpnn_gemm_tn_bf16")
     return out
 
 

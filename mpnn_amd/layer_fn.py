@@ -116,19 +116,17 @@ class _LayerFnBf16(torch.autograd.Function):
         # gz = gy * [y > 0] is a by-product of the first weight-gradient product (whole 256-byte rows)
         if g_wout is not None and gy.data_ptr() % 16 == 0:
             gz = torch.empty_like(gy)
-            gemm_tn_bf16(gy, x, mask=y, out=g_wout[:, :f], g_out=gz)
+            gemm_tn_bf16(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)   # both halves of gW_out in one pass over gy
         else:
             gz = torch.ops.aten.threshold_backward(gy, y, 0)
             if g_wout is not None:
-                g_wout[:, :f] = gz.t().mm(x)
+                torch.mm(gz.t(), torch.cat([x, aggr], 1), out=g_wout)
         ga = gemm_nt_bf16(gz, wt[f:], emul=cnt, out2=g_ab[:, :h])
         g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = gemm_nt_bf16(gz, wt[:f], g_ab, w_nodes.t().contiguous())
         g_wn = gemm_tn_bf16(g_ab, x) if ctx.needs_input_grad[2] else None
-        if g_wout is not None:
-            gemm_tn_bf16(gz, aggr, out=g_wout[:, f:])
         return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
 
 

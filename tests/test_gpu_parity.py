@@ -517,3 +517,6 @@ def test_gemm_tn_bf16(n, m, k):
     assert torch.equal(again, got.contiguous()), "weight gradient is not bitwise reproducible"
     plain = gemm_tn_bf16(g.cuda(), x.cuda())
     assert_close(plain.float(), g.double().t() @ x.double(), 2.0 ** -8, what="gemm_tn_bf16 unmasked")
+    x2 = bf(n, 24)
+    both = gemm_tn_bf16(g.cuda(), x.cuda(), mask=mask.cuda(), x2=x2.cuda())
+    assert_close(both.float(), gz.t() @ torch.cat([x, x2], 1).double(), 2.0 ** -8, what="gemm_tn_bf16 two matrices")
