@@ -812,6 +812,177 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
     }
 }
 
+// Two output tiles per block of 8 waves, sharing one operand slab in LDS: PAIR_K = one 128-row tile of G^T
+// against two 128-column tiles of [X | X2] (G and its mask are read once for both), otherwise two row tiles
+// against one column tile (X is read once for both).  Waves 0-3 own the first tile, waves 4-7 the second.
+// Separate blocks for the two tiles read the shared operand twice from HBM: their slabs drift apart and the
+// working set of all resident blocks does not fit the L2.
+constexpr int kTr2Stage = 9 * kTrPlane;   // 3 tile-wide matrices x 3 pieces
+
+struct TnPane {   // one 128-column wide part of an operand
+  const float* p; int64_t ld; int width; int c0; int out0; bool ok;
+};
+
+template <bool MASKED, bool PAIR_K>
+__global__ void __launch_bounds__(2 * kBlock) k_gemm_tn_tr2(TnArgs a) {
+  constexpr int NG = PAIR_K ? 1 : 2, NX = PAIR_K ? 2 : 1;
+  constexpr int D = 4;
+  extern __shared__ float lds_f[];
+  char* const lds = reinterpret_cast<char*>(lds_f);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tw = wid >> 2;                                  // which of the two tiles this wave owns
+  const int wm = ((wid >> 1) & 1) * 64, wk = (wid & 1) * 64;
+
+  TnPane gp[NG], xp[NX];
+#pragma unroll
+  for (int t = 0; t < NG; ++t) {
+    const int m0 = ((PAIR_K ? 1 : 2) * (int)blockIdx.y + t) * 128;
+    gp[t] = TnPane{a.G, a.ldg, a.M, m0, m0, m0 < a.M};
+  }
+  const int z1 = (a.K + 127) / 128, z2 = a.X2 ? (a.K2 + 127) / 128 : 0;
+#pragma unroll
+  for (int t = 0; t < NX; ++t) {
+    const int z = (PAIR_K ? 2 : 1) * (int)blockIdx.z + t;
+    if (z < z1) xp[t] = TnPane{a.X, a.ldx, a.K, z * 128, z * 128, true};
+    else if (z < z1 + z2) xp[t] = TnPane{a.X2, a.ldx2, a.K2, (z - z1) * 128, a.K + (z - z1) * 128, true};
+    else xp[t] = TnPane{a.X, a.ldx, a.K, 0, 0, false};
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // a thread moves one float4 per pane and slab: row tid / 32, columns 4 (tid % 32) ..
+  const int pr = tid >> 5, pc = (tid & 31) * 4;
+  uint32_t gcol[NG], xcol[NX];
+#pragma unroll
+  for (int t = 0; t < NG; ++t) gcol[t] = (gp[t].ok && gp[t].c0 + pc < gp[t].width) ? gp[t].c0 + pc : 0;
+#pragma unroll
+  for (int t = 0; t < NX; ++t) xcol[t] = (xp[t].ok && xp[t].c0 + pc < xp[t].width) ? xp[t].c0 + pc : 0;
+  float4 gr[D][NG], mr[MASKED ? D : 1][NG], xr[D][NX];
+  auto fetch = [&](auto S, int64_t n0) {   // unconditional loads, scalar slab base + 32-bit lane offsets
+    constexpr int st = decltype(S)::value;
+    const int64_t left = a.N - 1 - n0;
+    const int rt_max = left < kTrRows - 1 ? (left < 0 ? 0 : (int)left) : kTrRows - 1;
+    const int64_t rbase = n0 < a.N ? n0 : a.N - 1;
+    const uint32_t r = pr < rt_max ? pr : rt_max;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      gr[st][t] = *reinterpret_cast<const float4*>(gp[t].p + rbase * gp[t].ld + (r * (uint32_t)gp[t].ld + gcol[t]));
+      if constexpr (MASKED)
+        mr[st][t] = *reinterpret_cast<const float4*>(a.mask + rbase * a.ldm + (r * (uint32_t)a.ldm + gcol[t]));
+    }
+#pragma unroll
+    for (int t = 0; t < NX; ++t)
+      xr[st][t] = *reinterpret_cast<const float4*>(xp[t].p + rbase * xp[t].ld + (r * (uint32_t)xp[t].ld + xcol[t]));
+  };
+  auto stash = [&](auto S, int buf, int64_t nslab) {
+    constexpr int st = decltype(S)::value;
+    const bool emit = a.gout && blockIdx.z == 0;   // uniform
+    const bool row_ok = nslab + pr < a.N;          // rows and columns past the end must contribute exact zeros
+    char* dst = lds + buf * kTr2Stage + pr * kTrPitch + pc * 2;
+#pragma unroll
+    for (int t = 0; t < NG; ++t) {
+      const bool in = gp[t].ok && gp[t].c0 + pc < gp[t].width;   // widths are multiples of 4
+      float4 g = select4(gr[st][t], (row_ok && in) ? 15 : 0);
+      if constexpr (MASKED) g = relu_mask4(g, mr[st][t]);
+      if (emit && row_ok && in)   // the masked gradient, one whole 512-byte row per 32 lanes
+        *reinterpret_cast<float4*>(a.gout + (nslab + pr) * a.ldgo + gp[t].c0 + pc) = g;
+      uint2 pz[3];
+      split4(g, pz);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(dst + (3 * t + i) * kTrPlane) = pz[i];
+    }
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+      const bool in = xp[t].ok && xp[t].c0 + pc < xp[t].width;
+      uint2 pz[3];
+      split4(select4(xr[st][t], (row_ok && in) ? 15 : 0), pz);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(dst + (3 * (NG + t) + i) * kTrPlane) = pz[i];
+    }
+  };
+  const int s16 = lane & 15;
+  const int frag_off = (8 * lh + (s16 >> 2)) * kTrPitch + (16 * ((lane >> 4) & 1) + 4 * (s16 & 3)) * 2;
+  const int gsel = PAIR_K ? 0 : tw, xsel = PAIR_K ? tw : 0;
+  auto multiply = [&](int buf) {
+    const char* gbase = lds + buf * kTr2Stage + 3 * gsel * kTrPlane + frag_off + wm * 2;
+    const char* xbase = lds + buf * kTr2Stage + 3 * (NG + xsel) * kTrPlane + frag_off + wk * 2;
+    bf16x8 ap[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ap[i][p] = read_tr8(gbase + p * kTrPlane + i * 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 bp[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bp[p] = read_tr8(xbase + p * kTrPlane + j * 64);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {   // smallest terms first
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[1], c, 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
+      }
+    }
+  };
+
+  const int64_t step = (int64_t)gridDim.x * kTrRows;
+  const int64_t first = (int64_t)blockIdx.x * kTrRows;
+  const int64_t total = first < a.N ? (a.N - first + step - 1) / step : 0;   // slabs of this block
+  auto body = [&](auto S, int64_t it) {
+    constexpr int st = decltype(S)::value;   // == it % D: the set slab `it` left when it was stashed
+    using Next = std::integral_constant<int, (st + 1) % D>;
+    const int64_t n0 = first + it * step;
+    const int buf = (int)(it & 1);
+    fetch(S, n0 + D * step);
+    multiply(buf);
+    if (it + 1 < total) stash(Next{}, buf ^ 1, n0 + step);
+    __syncthreads();
+  };
+  if (total > 0) {   // uniform over the block
+    fetch(std::integral_constant<int, 0>{}, first);
+    fetch(std::integral_constant<int, 1>{}, first + step);
+    fetch(std::integral_constant<int, 2>{}, first + 2 * step);
+    fetch(std::integral_constant<int, 3>{}, first + 3 * step);
+    stash(std::integral_constant<int, 0>{}, 0, first);
+    __syncthreads();
+    for (int64_t it = 0; it < total; it += D) {
+      body(std::integral_constant<int, 0>{}, it);
+      if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
+      if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
+      if (it + 3 < total) body(std::integral_constant<int, 3>{}, it + 3);
+    }
+  }
+  const TnPane& gw = gp[gsel];
+  const TnPane& xw = xp[xsel];
+  if (!gw.ok || !xw.ok) return;
+  const int ktot = a.K + a.K2;
+  float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cl = xw.c0 + wk + j * 32 + li;   // column inside the pane's matrix
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = gw.c0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < a.M && cl < xw.width) out[(int64_t)row * ktot + (xw.out0 - xw.c0) + cl] = acc[i][j][r];
+      }
+    }
+}
+
 // dW[m, k] = sum over slabs of partial[b][m][k] in a fixed order: each wave of a block takes the slabs
 // b = wave, wave + 4, ... (ascending) for 64 consecutive outputs, then the four wave sums are added in wave order.
 __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict__ partial, int nslabs, int M, int K,
@@ -859,6 +1030,12 @@ static bool gemm_split() {
 static bool tn_lds_split() {
   const char* e = getenv("MPNN_GEMM_TN");
   return e && e[0] == 'r';
+}
+
+// MPNN_GEMM_TN=single keeps one output tile per block (kept for comparison).
+static bool tn_pairs() {
+  const char* e = getenv("MPNN_GEMM_TN");
+  return !(e && e[0] == 's');
 }
 
 static bool nt_aligned(const NtArgs& a) {
@@ -969,7 +1146,17 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: Gout needs 16-byte aligned operands and ldgo >= M");
   dim3 grid(slabs, (M + 127) / 128, ztiles);
   auto go = [&](auto kern) { kern<<<grid, kBlock, 0, stream>>>(a); };
-  if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true>) : go(k_gemm_tn_tr<false>);
+  if (aligned && gemm_split() && !tn_lds_split() && tn_pairs() && (ztiles > 1 || grid.y > 1)) {
+    // two tiles per 8-wave block along the dimension that has more than one (columns first: they share G and mask)
+    const bool pair_k = ztiles > 1;
+    dim3 grid2(slabs, pair_k ? grid.y : (grid.y + 1) / 2, pair_k ? (ztiles + 1) / 2 : ztiles);
+    auto go2 = [&](auto kern) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTr2Stage);
+      kern<<<grid2, 2 * kBlock, 2 * kTr2Stage, stream>>>(a);
+    };
+    if (pair_k) mask ? go2(k_gemm_tn_tr2<true, true>) : go2(k_gemm_tn_tr2<false, true>);
+    else mask ? go2(k_gemm_tn_tr2<true, false>) : go2(k_gemm_tn_tr2<false, false>);
+  } else if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true>) : go(k_gemm_tn_tr<false>);
   else if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true>) : go(k_gemm_tn<true, true, false>);
   else if (aligned) mask ? go(k_gemm_tn<true, false, true>) : go(k_gemm_tn<true, false, false>);
   else mask ? go(k_gemm_tn<false, false, true>) : go(k_gemm_tn<false, false, false>);
