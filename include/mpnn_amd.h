@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 5
+#define MPNN_ABI_VERSION 6
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -311,6 +311,9 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
  *   the bfloat16 matrix cores with float32 accumulation (six piece products per product; error against a
  *   float64 product no larger than the float32 matrix cores'); MPNN_GEMM=f32 in the environment selects the
  *   float32 matrix-core instructions, which unaligned operands (K % 4 != 0) always take.
+ *   scratch (optional, 16-byte aligned, at least mpnn_gemm_nt_scratch_bytes(M, K1, K2) bytes): with it the
+ *   weights are split once per call into chunk images that the kernel copies straight into LDS, instead of
+ *   being split again by every block for every 128-row step.
  * mpnn_gemm_tn_f32:  dW[M,K] = (G * (mask > 0))[N,M]^T X[N,K]  (weight gradient; rows are summed in a fixed
  *   order through `scratch`, float, at least mpnn_gemm_tn_scratch_floats(N, M, K) elements).
  *   X2 (optional, [N,K2], K2 = 0 without it): dW[M, K+K2] = (G * (mask > 0))^T [X | X2] in one pass over G
@@ -323,7 +326,9 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
                          const float* W1, int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2,
                          const float* mask2, int64_t ldm2, const float* W2, int64_t ldw2, int32_t K2,
                          float* Y, int64_t ldy, const float* emul, int64_t ldemul, float* Y2,
-                         int64_t ldy2, int64_t N, int32_t M, int32_t relu, mpnn_stream_t stream);
+                         int64_t ldy2, int64_t N, int32_t M, int32_t relu, void* scratch,
+                         mpnn_stream_t stream);
+int64_t mpnn_gemm_nt_scratch_bytes(int32_t M, int32_t K1, int32_t K2);
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K);
 int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm,
                          const float* X, int64_t ldx, const float* X2, int64_t ldx2, float* dW,

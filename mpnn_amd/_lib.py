@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -84,7 +84,8 @@ SIGNATURES = {
     "mpnn_gemm_nt_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32,
-                                   c_int32, c_void_p]),
+                                   c_int32, c_void_p, c_void_p]),
+    "mpnn_gemm_nt_scratch_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "mpnn_gemm_nt_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                     c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_int64, c_int32, c_int32, c_void_p]),

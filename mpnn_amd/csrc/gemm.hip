@@ -24,6 +24,7 @@
 namespace mpnn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBK = 32;         // k-chunk staged per step (floats)
 constexpr int kLd = kBK + 4;    // LDS row stride: 36 floats = 9 sixteen-byte slots (odd => conflict-free b128)
@@ -44,6 +45,7 @@ struct NtArgs {
   float* Y2; int64_t ldy2;
   int64_t N; int M;
   int relu;
+  const char* wimg;   // optional: the weights split once per call into chunk images (k_split_weights)
 };
 
 // Branch-free 4-float load at columns k..k+3 of a row of K floats.  The address is clamped into the row so
@@ -134,15 +136,19 @@ __device__ __forceinline__ void split4(float4 v, uint2 (&p)[3]) {
   }
 }
 
-template <int MT, int WC, bool ALIGNED, bool STAGED, bool SPLIT, bool MASKED>
+template <int MT, int WC, bool ALIGNED, bool STAGED, bool SPLIT, bool MASKED, bool PRE = false>
 __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
   static_assert(!SPLIT || ALIGNED, "the split form needs 16-byte aligned rows");
+  static_assert(!PRE || SPLIT, "pre-split weight images belong to the split form");
   constexpr int NTHREADS = kBlock * WC;
   constexpr int WROWS = 32 * MT * WC;
   constexpr int BK = SPLIT ? kSplitBK : kBK;
   constexpr int QPR = BK / 4;                                       // float4 per row and chunk
   constexpr int XQ = (kBN * QPR) / NTHREADS;                        // float4 of X per thread and chunk
-  constexpr int WQ = (WROWS * QPR + NTHREADS - 1) / NTHREADS;       // float4 of W per thread and chunk
+  // W per thread and chunk: float4 of the matrix itself, or (PRE) 16-byte parts of its chunk image, whose rows
+  // are the 96 payload bytes of an LDS row (3 pieces x 16 k x 2 B)
+  constexpr int WPARTS = WROWS * 6;
+  constexpr int WQ = PRE ? (WPARTS + NTHREADS - 1) / NTHREADS : (WROWS * QPR + NTHREADS - 1) / NTHREADS;
   constexpr int ROWB = SPLIT ? kSplitRowB : kLd * 4;                // bytes per LDS row
   constexpr int STAGEB = (kBN + WROWS) * ROWB;
   extern __shared__ float lds[];
@@ -174,7 +180,8 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
   // return in issue order, so within an iteration the weight load is issued BEFORE the X load: waiting for the
   // weights of chunk i + 1 then leaves the younger X loads in flight.
   constexpr int D = (SPLIT && !MASKED) ? 4 : 2;   // mask operands double the registers of a set
-  float4 xr[D][XQ], mr[MASKED ? D : 1][XQ], wreg[2][WQ];
+  float4 xr[D][XQ], mr[MASKED ? D : 1][XQ], wreg[PRE ? 1 : 2][PRE ? 1 : WQ];
+  u32x4 wpart[PRE ? 2 : 1][PRE ? WQ : 1];   // PRE: raw 16-byte parts of the weight chunk image
   int xk[D], xK[D], wk[2], wK[2];   // k origin and row length of the chunk a set holds (for the tail mask)
   bool masked[D];
   int64_t f_row0 = (int64_t)blockIdx.x * kBN;   // position of the next X fetch in the (row step, chunk) sequence
@@ -231,7 +238,15 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
     const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
     wk[ws] = (c < nch0 ? c : c - nch0) * BK;
     wK[ws] = sg.K;
-    if constexpr (ALIGNED) {
+    if constexpr (PRE) {
+      const char* img = a.wimg + ((int64_t)blockIdx.y * nch + c) * (WPARTS * 16);
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) {
+        int idx = tid + NTHREADS * q;
+        idx = idx < WPARTS ? idx : WPARTS - 1;
+        wpart[ws][q] = *reinterpret_cast<const u32x4*>(img + idx * 16);
+      }
+    } else if constexpr (ALIGNED) {
       const int r_max = a.M - 1 - m0 < WROWS - 1 ? a.M - 1 - m0 : WROWS - 1;
       const float* wb = sg.W + (int64_t)m0 * sg.ldw;
       const uint32_t ldw = (uint32_t)sg.ldw;
@@ -280,12 +295,20 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
       if constexpr (MASKED) v = relu_mask4(v, mr[st][q]);  // relu backward fused into the operand (ones if unmasked)
       put(Xs, idx, v);
     }
+    if constexpr (PRE) {   // already split and zero-padded: a plain copy into the LDS rows
 #pragma unroll
-    for (int q = 0; q < WQ; ++q) {
-      const int idx = tid + NTHREADS * q;
-      float4 v = wreg[ws][q];
-      if (w_tail) v = select4(v, valid4(wk[ws] + (idx % QPR) * 4, wK[ws], true));
-      if (idx / QPR < WROWS) put(Ws, idx, v);
+      for (int q = 0; q < WQ; ++q) {
+        const int idx = tid + NTHREADS * q;
+        if (idx < WPARTS) *reinterpret_cast<u32x4*>(Ws + (idx / 6) * ROWB + (idx % 6) * 16) = wpart[ws][q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < WQ; ++q) {
+        const int idx = tid + NTHREADS * q;
+        float4 v = wreg[ws][q];
+        if (w_tail) v = select4(v, valid4(wk[ws] + (idx % QPR) * 4, wK[ws], true));
+        if (idx / QPR < WROWS) put(Ws, idx, v);
+      }
     }
   };
 
@@ -447,6 +470,27 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
       if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
       if (it + 3 < total) body(std::integral_constant<int, 3>{}, it + 3);
     }
+  }
+}
+
+// One block per (column block, 16-wide chunk): the chunk's weight rows as their three bfloat16 pieces, 96 bytes per
+// row in the order of an LDS row of k_gemm_nt's split form; rows and columns past the end are zeros.
+__global__ void __launch_bounds__(kBlock) k_split_weights(NtArgs a, char* __restrict__ out, int wrows) {
+  const int nch0 = (a.seg[0].K + kSplitBK - 1) / kSplitBK;
+  const int nch = nch0 + (a.nseg > 1 ? (a.seg[1].K + kSplitBK - 1) / kSplitBK : 0);
+  const int cb = blockIdx.x / nch, c = blockIdx.x % nch;
+  const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
+  const int k0 = (c < nch0 ? c : c - nch0) * kSplitBK;
+  char* img = out + (int64_t)blockIdx.x * wrows * 96;
+  for (int idx = threadIdx.x; idx < wrows * (kSplitBK / 4); idx += kBlock) {
+    const int r = idx / (kSplitBK / 4), q = idx % (kSplitBK / 4);
+    const int m = cb * wrows + r, kk = k0 + q * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < a.M && kk < sg.K) v = *reinterpret_cast<const float4*>(sg.W + (int64_t)m * sg.ldw + kk);
+    uint2 pz[3];
+    split4(v, pz);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(img + r * 96 + i * (kSplitBK * 2) + q * 8) = pz[i];
   }
 }
 
@@ -1032,6 +1076,12 @@ static bool tn_lds_split() {
   return e && e[0] == 'r';
 }
 
+// MPNN_GEMM_NT=nosplit keeps the per-chunk weight split inside the kernel even when scratch is given (comparison).
+static bool nt_presplit() {
+  const char* e = getenv("MPNN_GEMM_NT");
+  return !(e && e[0] == 'n');
+}
+
 // MPNN_GEMM_TN=single keeps one output tile per block (kept for comparison).
 static bool tn_pairs() {
   const char* e = getenv("MPNN_GEMM_TN");
@@ -1048,7 +1098,14 @@ static bool nt_aligned(const NtArgs& a) {
 }
 
 template <int MT, int WC>
-static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
+static int64_t nt_scratch_bytes(int M, int K1, int K2) {
+  constexpr int WROWS = 32 * MT * WC;
+  const int64_t nch = (K1 + kSplitBK - 1) / kSplitBK + (K2 + kSplitBK - 1) / kSplitBK;
+  return (int64_t)((M + WROWS - 1) / WROWS) * nch * WROWS * 96;
+}
+
+template <int MT, int WC>
+static void launch_nt(NtArgs& a, bool aligned, hipStream_t stream) {
   int64_t blocks = (a.N + kBN - 1) / kBN;
   if (blocks > 1024) blocks = 1024;
   constexpr int WROWS = 32 * MT * WC;
@@ -1061,13 +1118,23 @@ static void launch_nt(const NtArgs& a, bool aligned, hipStream_t stream) {
   constexpr size_t kPatches = (size_t)4 * WC * 32 * 36 * sizeof(float);   // one 32 x 32 patch (pitch 36) per wave
   constexpr size_t lds_split = (size_t)2 * (kBN + WROWS) * kSplitRowB;
   constexpr bool split_can_stage = (kBN + WROWS) * kSplitRowB >= kPatches;   // not the narrowest tile (MT = 1)
+  const bool split_form = aligned && gemm_split() && (!a.Y2 || (staged && split_can_stage));
+  const bool pre = split_form && a.wimg != nullptr && nt_presplit();
+  if (pre) {
+    const int nch = (a.seg[0].K + kSplitBK - 1) / kSplitBK + (a.nseg > 1 ? (a.seg[1].K + kSplitBK - 1) / kSplitBK : 0);
+    k_split_weights<<<grid.y * nch, kBlock, 0, stream>>>(a, const_cast<char*>(a.wimg), WROWS);
+  } else {
+    a.wimg = nullptr;
+  }
   if (aligned && gemm_split() && !a.Y2) {
-    has_mask ? go(k_gemm_nt<MT, WC, true, false, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, false, true, false>, lds_split);
+    if (pre) has_mask ? go(k_gemm_nt<MT, WC, true, false, true, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, false, true, false, true>, lds_split);
+    else has_mask ? go(k_gemm_nt<MT, WC, true, false, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, false, true, false>, lds_split);
     return;
   }
   if constexpr (split_can_stage) {
     if (aligned && gemm_split() && staged) {
-      has_mask ? go(k_gemm_nt<MT, WC, true, true, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, true, true, false>, lds_split);
+      if (pre) has_mask ? go(k_gemm_nt<MT, WC, true, true, true, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, true, true, false, true>, lds_split);
+      else has_mask ? go(k_gemm_nt<MT, WC, true, true, true, true>, lds_split) : go(k_gemm_nt<MT, WC, true, true, true, false>, lds_split);
       return;
     }
   }
@@ -1095,7 +1162,7 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
                          int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2, const float* mask2, int64_t ldm2,
                          const float* W2, int64_t ldw2, int32_t K2, float* Y, int64_t ldy, const float* emul,
                          int64_t ldemul, float* Y2, int64_t ldy2, int64_t N, int32_t M, int32_t relu,
-                         mpnn_stream_t stream) {
+                         void* scratch, mpnn_stream_t stream) {
   if (N < 0 || M < 1 || K1 < 1 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: bad sizes");
   if (N == 0) return MPNN_OK;
   if (!X1 || !W1 || !Y || (K2 > 0 && (!X2 || !W2))) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: null pointer argument");
@@ -1108,6 +1175,8 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
   if (Y2 && (!emul || ldemul < M || ldy2 < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: Y2 needs emul and ld >= M");
   a.Y = Y; a.ldy = ldy; a.emul = emul; a.ldemul = ldemul; a.Y2 = Y2; a.ldy2 = ldy2;
   a.N = N; a.M = M; a.relu = relu;
+  if (scratch && ((uintptr_t)scratch & 15)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: scratch must be 16-byte aligned");
+  a.wimg = static_cast<const char*>(scratch);
   const bool aligned = nt_aligned(a);
   if (M <= 32) launch_nt<1, 1>(a, aligned, stream);
   else if (M <= 64) launch_nt<2, 1>(a, aligned, stream);
@@ -1115,6 +1184,14 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
   else launch_nt<4, 2>(a, aligned, stream);
   MPNN_LAUNCH_CHECK("k_gemm_nt");
   return MPNN_OK;
+}
+
+int64_t mpnn_gemm_nt_scratch_bytes(int32_t M, int32_t K1, int32_t K2) {
+  if (M < 1 || K1 < 1 || K2 < 0) return -1;
+  if (M <= 32) return nt_scratch_bytes<1, 1>(M, K1, K2);
+  if (M <= 64) return nt_scratch_bytes<2, 1>(M, K1, K2);
+  if (M <= 128) return nt_scratch_bytes<4, 1>(M, K1, K2);
+  return nt_scratch_bytes<4, 2>(M, K1, K2);
 }
 
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K) {   // K = K + K2 of the call

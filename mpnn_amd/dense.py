@@ -25,6 +25,20 @@ def _scratch(n: int, device) -> torch.Tensor:
     return buf
 
 
+_WSPLIT = {}
+
+
+def _wsplit(nbytes: int, device) -> torch.Tensor:
+    """Room for the split weight images of one NT product.  One buffer per device and stream-ordered reuse: every
+    call rewrites it before its own GEMM reads it, on the stream both run on."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WSPLIT.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WSPLIT[key] = buf
+    return buf
+
+
 def _rows(t: torch.Tensor) -> torch.Tensor:
     return t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()
 
@@ -43,6 +57,8 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=N
         x2, w2 = _rows(x2), _rows(w2)
     mask1 = _rows(mask1) if mask1 is not None else None
     mask2 = _rows(mask2) if mask2 is not None else None
+    k2 = x2.size(1) if x2 is not None else 0
+    wimg = _wsplit(lib.mpnn_gemm_nt_scratch_bytes(m, k1, k2), x1.device)
     _lib.check(lib.mpnn_gemm_nt_f32(
         _lib.ptr(x1), x1.stride(0), _lib.ptr(mask1), mask1.stride(0) if mask1 is not None else 0, _lib.ptr(w1),
         w1.stride(0), k1,
@@ -50,7 +66,8 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=N
         mask2.stride(0) if mask2 is not None else 0, _lib.ptr(w2), w2.stride(0) if w2 is not None else 0,
         x2.size(1) if x2 is not None else 0,
         _lib.ptr(y), y.stride(0), _lib.ptr(emul), emul.stride(0) if emul is not None else 0, _lib.ptr(out2),
-        out2.stride(0) if out2 is not None else 0, n, m, 1 if relu else 0, _lib.stream_handle(x1.device)),
+        out2.stride(0) if out2 is not None else 0, n, m, 1 if relu else 0, _lib.ptr(wimg),
+        _lib.stream_handle(x1.device)),
         "mpnn_gemm_nt_f32")
     return y
 
