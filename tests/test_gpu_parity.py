@@ -520,3 +520,40 @@ def test_gemm_tn_bf16(n, m, k):
     x2 = bf(n, 24)
     both = gemm_tn_bf16(g.cuda(), x.cuda(), mask=mask.cuda(), x2=x2.cuda())
     assert_close(both.float(), gz.t() @ torch.cat([x, x2], 1).double(), 2.0 ** -8, what="gemm_tn_bf16 two matrices")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,m", [(1000, 64, 32), (3001, 128, 64), (5000, 128, 128), (2049, 36, 256), (700, 11, 16)])
+def test_gemm_nt_second_output(n, k, m, dev):
+    """Y and Y2 = Y * emul from one call (the epilogue staged through LDS for every tile width, and the plain
+    epilogue for unaligned operands), with relu, into a column slice of a wider matrix."""
+    from mpnn_amd.dense import gemm_nt
+    gen = torch.Generator().manual_seed(n + m)
+    x, w = torch.randn(n, k, generator=gen), torch.randn(m, k, generator=gen)
+    emul = torch.randint(0, 50, (n, m), generator=gen).float()
+    want = (x.double() @ w.double().t()).relu()
+    wide = torch.zeros(n, 2 * m, device=dev)
+    got = gemm_nt(x.to(dev), w.to(dev), relu=True, emul=emul.to(dev), out2=wide[:, :m])
+    assert_close(got, want, RTOL32, what="Y")
+    assert_close(wide[:, :m], want * emul.double(), RTOL32, what="Y2")
+    assert float(wide[:, m:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_gemm_variants_agree(monkeypatch, dev):
+    """The forms kept for comparison (weights split inside the kernel, one output tile per block) agree with the
+    defaults: NT bit for bit (same arithmetic, other data path), TN to float32 rounding (other slab grouping)."""
+    from mpnn_amd.dense import gemm_nt, gemm_tn
+    gen = torch.Generator().manual_seed(3)
+    n = 6000
+    x, x2, w = (torch.randn(n, 128, generator=gen).to(dev), torch.randn(n, 64, generator=gen).to(dev),
+                torch.randn(128, 192, generator=gen).to(dev))
+    g, mask = torch.randn(n, 256, generator=gen).to(dev), torch.randn(n, 256, generator=gen).to(dev)
+    y = gemm_nt(x, w[:, :128], x2, w[:, 128:], relu=True)
+    dw = gemm_tn(g, x, mask=mask, x2=x2)
+    monkeypatch.setenv("MPNN_GEMM_NT", "nosplit")
+    assert torch.equal(gemm_nt(x, w[:, :128], x2, w[:, 128:], relu=True), y)
+    monkeypatch.delenv("MPNN_GEMM_NT")
+    for form in ("single", "regs"):
+        monkeypatch.setenv("MPNN_GEMM_TN", form)
+        assert_close(gemm_tn(g, x, mask=mask, x2=x2), dw.double().cpu(), RTOL32, what=f"TN form {form}")
