@@ -1082,6 +1082,15 @@ static bool nt_presplit() {
   return !(e && e[0] == 'n');
 }
 
+template <bool MASKED, bool PAIR_K>
+static void launch_tn_pair(dim3 grid, const TnArgs& a, hipStream_t stream) {
+  // more than 64 KiB of dynamic LDS needs the attribute; set once per kernel (the call is far slower than a launch)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_tr2<MASKED, PAIR_K>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTr2Stage);
+  (void)attr;
+  k_gemm_tn_tr2<MASKED, PAIR_K><<<grid, 2 * kBlock, 2 * kTr2Stage, stream>>>(a);
+}
+
 // MPNN_GEMM_TN=single keeps one output tile per block (kept for comparison).
 static bool tn_pairs() {
   const char* e = getenv("MPNN_GEMM_TN");
@@ -1223,16 +1232,14 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: Gout needs 16-byte aligned operands and ldgo >= M");
   dim3 grid(slabs, (M + 127) / 128, ztiles);
   auto go = [&](auto kern) { kern<<<grid, kBlock, 0, stream>>>(a); };
-  if (aligned && gemm_split() && !tn_lds_split() && tn_pairs() && (ztiles > 1 || grid.y > 1)) {
+  // Pairing pays once a block walks many slabs (it halves the traffic of the shared operand); on short matrices
+  // the 8-wave blocks' start-up and barriers cost more than the re-read, which the caches absorb there.
+  if (aligned && gemm_split() && !tn_lds_split() && tn_pairs() && (ztiles > 1 || grid.y > 1) && N >= ((int64_t)1 << 19)) {
     // two tiles per 8-wave block along the dimension that has more than one (columns first: they share G and mask)
     const bool pair_k = ztiles > 1;
     dim3 grid2(slabs, pair_k ? grid.y : (grid.y + 1) / 2, pair_k ? (ztiles + 1) / 2 : ztiles);
-    auto go2 = [&](auto kern) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTr2Stage);
-      kern<<<grid2, 2 * kBlock, 2 * kTr2Stage, stream>>>(a);
-    };
-    if (pair_k) mask ? go2(k_gemm_tn_tr2<true, true>) : go2(k_gemm_tn_tr2<false, true>);
-    else mask ? go2(k_gemm_tn_tr2<true, false>) : go2(k_gemm_tn_tr2<false, false>);
+    if (pair_k) mask ? launch_tn_pair<true, true>(grid2, a, stream) : launch_tn_pair<false, true>(grid2, a, stream);
+    else mask ? launch_tn_pair<true, false>(grid2, a, stream) : launch_tn_pair<false, false>(grid2, a, stream);
   } else if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true>) : go(k_gemm_tn_tr<false>);
   else if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true>) : go(k_gemm_tn<true, true, false>);
   else if (aligned) mask ? go(k_gemm_tn<true, false, true>) : go(k_gemm_tn<true, false, false>);

@@ -256,9 +256,11 @@ static void launch_nt_bf16(const NtBf16Args& a, hipStream_t stream) {
   constexpr int WROWS = 32 * MT * WC;
   dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
   const size_t lds = (size_t)2 * (kBfBN + WROWS) * kBfRowB;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<MT, WC>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 64 * 1024) {   // set once per kernel: the call is far slower than a launch
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<MT, WC>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+  }
   k_gemm_nt_bf16<MT, WC><<<grid, kBlock * WC, lds, stream>>>(a);
 }
 

@@ -13,6 +13,14 @@ from .layers import MPNNLayerCat, MPNNLayerSum
 from .ops import global_mean_pool
 
 
+def _relu_after(layer, x):
+    """x = F.relu(x) after a layer (models/mpnn.py:48,98,144).  Both layer classes end in relu(linear_out(..)), and
+    relu of a relu output is the identity in the forward (x >= 0) and in the backward (the layer applies the same
+    mask [x > 0] to the incoming gradient), so the two elementwise passes over [N, H] are skipped for them - the
+    results are bit for bit those of the literal call."""
+    return x if isinstance(layer, (MPNNLayerCat, MPNNLayerSum)) else F.relu(x)
+
+
 def _make_layers(in_channels, edge_channels, hidden_channels, num_layers, mode):
     cls = MPNNLayerCat if mode == 'cat' else MPNNLayerSum
     layers = torch.nn.ModuleList()
@@ -32,8 +40,7 @@ class MPNN(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         for layer in self.layers:
-            x = layer(x, edge_index, edge_attr)
-            x = F.relu(x)
+            x = _relu_after(layer, layer(x, edge_index, edge_attr))
         return self.output_layer(x)
 
 
@@ -46,8 +53,7 @@ class _PooledMPNN(torch.nn.Module):
 
     def forward(self, x, edge_index, batch, edge_attr):
         for layer in self.layers:
-            x = layer(x, edge_index, edge_attr)
-            x = F.relu(x)
+            x = _relu_after(layer, layer(x, edge_index, edge_attr))
         x = global_mean_pool(x, batch)
         return self.output_layer(x)
 

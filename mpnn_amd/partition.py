@@ -191,7 +191,7 @@ def partitioned_model(model, x_local, pg: PartitionedGraph, edge_attr_local, gro
     """MPNN.forward (reference models/mpnn.py:86-101) on the local range; returns the local rows of the logits."""
     x = x_local
     for layer in model.layers:
-        x = F.relu(partitioned_layer(layer, x, pg, edge_attr_local, group, aggregate_fn))
+        x = partitioned_layer(layer, x, pg, edge_attr_local, group, aggregate_fn)   # ends in a relu: F.relu(x) is the identity
     return model.output_layer(x)
 
 

@@ -366,7 +366,8 @@ def test_gemm_nt(n, k1, k2, m, relu, dev):
     assert_close(got, want, RTOL32, what="gemm_nt")
 
 
-@pytest.mark.parametrize("n,m,k", [(5000, 256, 128), (3001, 64, 500), (100, 64, 11), (33, 7, 3), (4096, 128, 130)])
+@pytest.mark.parametrize("n,m,k", [(5000, 256, 128), (3001, 64, 500), (100, 64, 11), (33, 7, 3), (4096, 128, 130),
+                                   (600_000, 256, 64)])   # the last: two row tiles per block
 def test_gemm_tn(n, m, k, dev):
     from mpnn_amd.dense import gemm_tn
     gen = torch.Generator().manual_seed(n + k)
@@ -380,7 +381,9 @@ def test_gemm_tn(n, m, k, dev):
     assert torch.equal(again, got.contiguous()), "weight gradient is not bitwise reproducible"
 
 
-@pytest.mark.parametrize("n,m,k,k2", [(5000, 128, 128, 128), (3001, 64, 500, 64), (700, 16, 11, 16), (2048, 256, 132, 4)])
+# the last two are long enough (>= 2^19 rows) for the kernel that computes two tiles per block, one with an odd tile count
+@pytest.mark.parametrize("n,m,k,k2", [(5000, 128, 128, 128), (3001, 64, 500, 64), (700, 16, 11, 16), (2048, 256, 132, 4),
+                                      (530_000, 128, 128, 128), (524_295, 160, 132, 4)])
 def test_gemm_tn_two_right_hand_matrices(n, m, k, k2, dev):
     """dW = (g * [mask > 0])^T [x | x2] in one pass against float64 and against the two separate products (which
     may sum their row slabs in another grouping, hence not bit for bit)."""
