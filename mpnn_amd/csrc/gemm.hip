@@ -1128,7 +1128,8 @@ static void launch_nt(NtArgs& a, bool aligned, hipStream_t stream) {
   constexpr size_t lds_split = (size_t)2 * (kBN + WROWS) * kSplitRowB;
   constexpr bool split_can_stage = (kBN + WROWS) * kSplitRowB >= kPatches;   // not the narrowest tile (MT = 1)
   const bool split_form = aligned && gemm_split() && (!a.Y2 || (staged && split_can_stage));
-  const bool pre = split_form && a.wimg != nullptr && nt_presplit();
+  // splitting the weights in a launch of its own pays once blocks take several 128-row steps each
+  const bool pre = split_form && a.wimg != nullptr && nt_presplit() && a.N >= (int64_t)128 * 1024;
   if (pre) {
     const int nch = (a.seg[0].K + kSplitBK - 1) / kSplitBK + (a.nseg > 1 ? (a.seg[1].K + kSplitBK - 1) / kSplitBK : 0);
     k_split_weights<<<grid.y * nch, kBlock, 0, stream>>>(a, const_cast<char*>(a.wimg), WROWS);

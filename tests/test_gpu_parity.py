@@ -548,7 +548,7 @@ def test_gemm_variants_agree(monkeypatch, dev):
     defaults: NT bit for bit (same arithmetic, other data path), TN to float32 rounding (other slab grouping)."""
     from mpnn_amd.dense import gemm_nt, gemm_tn
     gen = torch.Generator().manual_seed(3)
-    n = 6000
+    n = 140_000   # long enough for the pre-split weight images (>= 2^17 rows)
     x, x2, w = (torch.randn(n, 128, generator=gen).to(dev), torch.randn(n, 64, generator=gen).to(dev),
                 torch.randn(128, 192, generator=gen).to(dev))
     g, mask = torch.randn(n, 256, generator=gen).to(dev), torch.randn(n, 256, generator=gen).to(dev)
