@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 6
+#define MPNN_ABI_VERSION 7
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -164,6 +164,16 @@ typedef struct mpnn_collate_desc {
   int32_t* eid_src;
   int32_t* items_src;
   int32_t* tpos;
+  /* Padded mode (node_capacity > 0): the outputs have node_capacity rows / edge_capacity edge entries whatever
+   * the batch holds, and the real totals are READ ON THE DEVICE from slots[0][num_slots] and slots[1][num_slots]
+   * (num_nodes / num_edges above are ignored), so a launch recorded in a HIP graph assembles batches of any size
+   * up to the capacity.  node_capacity must exceed the real node count.  Padding rows: x, pos = 0,
+   * batch = num_slots (a padding graph), empty CSR rows and work items; padding edge entries: both ends
+   * = node_capacity - 1 in edge_index and col (they belong to no CSR row), eid = tpos = own position,
+   * attributes 0.  pool_rowptr (optional, [num_slots + 2]): first node of every graph, then the real total,
+   * then node_capacity - the segment boundaries for pooling over batch, padding graph last. */
+  int64_t node_capacity, edge_capacity;
+  int32_t* pool_rowptr;
 } mpnn_collate_desc;
 int32_t mpnn_collate(const mpnn_collate_desc* desc, mpnn_stream_t stream);
 

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -34,6 +34,7 @@ class CollateDesc(ctypes.Structure):
         ("rowptr_dst", c_void_p), ("col_dst", c_void_p), ("eid_dst", c_void_p), ("items_dst", c_void_p),
         ("rowptr_src", c_void_p), ("col_src", c_void_p), ("eid_src", c_void_p), ("items_src", c_void_p),
         ("tpos", c_void_p),
+        ("node_capacity", c_int64), ("edge_capacity", c_int64), ("pool_rowptr", c_void_p),
     ]
 
 

@@ -34,16 +34,41 @@ __device__ __forceinline__ void copy_row(const void* src, int64_t srow, void* ds
 }
 
 template <typename W>
+__device__ __forceinline__ void zero_row(void* dst, int64_t drow, int row_bytes) {
+  const int words = row_bytes / (int)sizeof(W);
+  W* o = reinterpret_cast<W*>(dst) + drow * words;
+  for (int i = 0; i < words; ++i) o[i] = 0;
+}
+
+// PADDED: outputs of capacity size, real totals read from the slot table on the device (see the header).
+template <typename W, bool PADDED>
 __global__ void __launch_bounds__(kBlock) k_collate_nodes(CollateArgs a) {
   const mpnn_collate_desc& d = a.d;
   const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int B = d.num_slots;
-  if (p == d.num_nodes) {
-    d.rowptr_dst[p] = (int32_t)d.num_edges;
-    d.rowptr_src[p] = (int32_t)d.num_edges;
+  const int64_t n_real = PADDED ? (int64_t)d.slots[B] : d.num_nodes;
+  const int64_t e_real = PADDED ? (int64_t)d.slots[(B + 1) + B] : d.num_edges;
+  const int64_t n_out = PADDED ? d.node_capacity : d.num_nodes;
+  if (p == n_out) {
+    d.rowptr_dst[p] = (int32_t)e_real;
+    d.rowptr_src[p] = (int32_t)e_real;
   }
   if (p < B && d.y_all) copy_row<W>(d.y_all, d.slots[4 * (B + 1) + p], d.y, p, d.y_row_bytes);  // p as slot
-  if (p >= d.num_nodes) return;
+  if (PADDED && d.pool_rowptr) {
+    if (p <= B) d.pool_rowptr[p] = d.slots[p];
+    if (p == B + 1) d.pool_rowptr[p] = (int32_t)n_out;
+  }
+  if (p >= n_out) return;
+  if (PADDED && p >= n_real) {   // padding row
+    d.batch[p] = B;
+    d.rowptr_dst[p] = (int32_t)e_real;
+    d.rowptr_src[p] = (int32_t)e_real;
+    reinterpret_cast<int4*>(d.items_dst)[p] = make_int4((int32_t)p, (int32_t)e_real, (int32_t)e_real, -1);
+    reinterpret_cast<int4*>(d.items_src)[p] = make_int4((int32_t)p, (int32_t)e_real, (int32_t)e_real, -1);
+    zero_row<W>(d.x, p, d.x_row_bytes);
+    if (d.pos_all) zero_row<W>(d.pos, p, d.pos_row_bytes);
+    return;
+  }
   const int b = find_slot(d.slots, B, (int32_t)p);
   const int32_t dn = d.slots[2 * (B + 1) + b], de = d.slots[3 * (B + 1) + b];
   const int64_t v = p - dn;
@@ -62,17 +87,33 @@ __global__ void __launch_bounds__(kBlock) k_collate_nodes(CollateArgs a) {
   if (d.pos_all) copy_row<W>(d.pos_all, v, d.pos, p, d.pos_row_bytes);
 }
 
-template <typename W>
+template <typename W, bool PADDED>
 __global__ void __launch_bounds__(kBlock) k_collate_edges(CollateArgs a) {
   const mpnn_collate_desc& d = a.d;
   const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q >= d.num_edges) return;
   const int B = d.num_slots;
+  const int64_t e_real = PADDED ? (int64_t)d.slots[(B + 1) + B] : d.num_edges;
+  const int64_t e_out = PADDED ? d.edge_capacity : d.num_edges;   // also the row length of edge_index
+  if (q >= e_out) return;
+  if (PADDED && q >= e_real) {   // padding entry: outside every CSR row
+    const int64_t pad = d.node_capacity - 1;
+    d.edge_index[q] = pad;
+    d.edge_index[e_out + q] = pad;
+    d.col_dst[q] = (int32_t)pad;
+    d.col_src[q] = (int32_t)pad;
+    d.eid_dst[q] = (int32_t)q;
+    d.eid_src[q] = (int32_t)q;
+    d.tpos[q] = (int32_t)q;
+    zero_row<W>(d.ea, q, d.ea_row_bytes);
+    zero_row<W>(d.ea_dst, q, d.ea_row_bytes);
+    zero_row<W>(d.ea_src, q, d.ea_row_bytes);
+    return;
+  }
   const int b = find_slot(d.slots + (B + 1), B, (int32_t)q);
   const int32_t dn = d.slots[2 * (B + 1) + b], de = d.slots[3 * (B + 1) + b];
   const int64_t e = q - de;
   d.edge_index[q] = d.src_all[e] + dn;
-  d.edge_index[d.num_edges + q] = d.dst_all[e] + dn;
+  d.edge_index[e_out + q] = d.dst_all[e] + dn;
   d.col_dst[q] = d.col_dst_all[e] + dn;
   d.eid_dst[q] = d.eid_dst_all[e] + de;
   d.col_src[q] = d.col_src_all[e] + dn;
@@ -96,7 +137,7 @@ extern "C" int32_t mpnn_collate(const mpnn_collate_desc* desc, mpnn_stream_t str
   if (!d.slots || !d.x_all || !d.x || !d.batch || !d.rowptr_dst_all || !d.rowptr_src_all || !d.rowptr_dst ||
       !d.rowptr_src || !d.items_dst || !d.items_src)
     return fail(MPNN_E_INVALID, "mpnn_collate: null node-side pointer");
-  if (d.num_edges > 0 &&
+  if ((d.node_capacity > 0 ? d.edge_capacity : d.num_edges) > 0 &&
       (!d.src_all || !d.dst_all || !d.edge_index || !d.ea_all || !d.ea_dst_all || !d.ea_src_all || !d.ea || !d.ea_dst ||
        !d.ea_src || !d.col_dst_all || !d.eid_dst_all || !d.col_src_all || !d.eid_src_all || !d.tpos_all || !d.col_dst ||
        !d.eid_dst || !d.col_src || !d.eid_src || !d.tpos))
@@ -109,17 +150,33 @@ extern "C" int32_t mpnn_collate(const mpnn_collate_desc* desc, mpnn_stream_t str
     return fail(MPNN_E_INVALID, "mpnn_collate: row sizes must be positive multiples of 2 bytes");
   if (((uintptr_t)d.items_dst | (uintptr_t)d.items_src) & 15)
     return fail(MPNN_E_INVALID, "mpnn_collate: items arrays must be 16-byte aligned");
+  const bool padded = d.node_capacity > 0;
+  if (padded && (d.edge_capacity < 0 || d.node_capacity >= INT32_MAX || d.edge_capacity >= INT32_MAX))
+    return fail(MPNN_E_INVALID, "mpnn_collate: capacities %lld nodes, %lld edges", (long long)d.node_capacity,
+                (long long)d.edge_capacity);
+  const int64_t n_out = padded ? d.node_capacity : d.num_nodes, e_out = padded ? d.edge_capacity : d.num_edges;
   const bool w4 = !((d.x_row_bytes | d.ea_row_bytes | (d.pos_all ? d.pos_row_bytes : 0) | (d.y_all ? d.y_row_bytes : 0)) & 3);
   CollateArgs a{d};
-  const int64_t node_threads = (d.num_nodes + 1 > d.num_slots) ? d.num_nodes + 1 : d.num_slots;
+  int64_t node_threads = n_out + 1;
+  if (node_threads < d.num_slots + 2) node_threads = d.num_slots + 2;
   const unsigned gn = (unsigned)((node_threads + kBlock - 1) / kBlock);
-  if (w4) k_collate_nodes<uint32_t><<<gn, kBlock, 0, stream>>>(a);
-  else k_collate_nodes<uint16_t><<<gn, kBlock, 0, stream>>>(a);
+  if (padded) {
+    if (w4) k_collate_nodes<uint32_t, true><<<gn, kBlock, 0, stream>>>(a);
+    else k_collate_nodes<uint16_t, true><<<gn, kBlock, 0, stream>>>(a);
+  } else {
+    if (w4) k_collate_nodes<uint32_t, false><<<gn, kBlock, 0, stream>>>(a);
+    else k_collate_nodes<uint16_t, false><<<gn, kBlock, 0, stream>>>(a);
+  }
   MPNN_LAUNCH_CHECK("k_collate_nodes");
-  if (d.num_edges > 0) {
-    const unsigned ge = (unsigned)((d.num_edges + kBlock - 1) / kBlock);
-    if (w4) k_collate_edges<uint32_t><<<ge, kBlock, 0, stream>>>(a);
-    else k_collate_edges<uint16_t><<<ge, kBlock, 0, stream>>>(a);
+  if (e_out > 0) {
+    const unsigned ge = (unsigned)((e_out + kBlock - 1) / kBlock);
+    if (padded) {
+      if (w4) k_collate_edges<uint32_t, true><<<ge, kBlock, 0, stream>>>(a);
+      else k_collate_edges<uint16_t, true><<<ge, kBlock, 0, stream>>>(a);
+    } else {
+      if (w4) k_collate_edges<uint32_t, false><<<ge, kBlock, 0, stream>>>(a);
+      else k_collate_edges<uint16_t, false><<<ge, kBlock, 0, stream>>>(a);
+    }
     MPNN_LAUNCH_CHECK("k_collate_edges");
   }
   return MPNN_OK;

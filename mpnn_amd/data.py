@@ -29,6 +29,7 @@ class Batch:
         self.num_graphs = num_graphs
         self.num_nodes = x.size(0)
         self._parts = None
+        self.capacity = None   # (nodes, edges) of a padded batch, see GraphStore.collate
 
     def to(self, device):
         if torch.device(device).type != self.x.device.type:
@@ -127,59 +128,93 @@ class GraphStore:
     def slot_table(self, ids) -> np.ndarray:
         return slot_table(self.node_ptr, self.edge_ptr, ids)
 
-    def collate(self, ids, out: Batch | None = None) -> Batch:
+    def capacity_for(self, batch_size: int) -> tuple:
+        """(nodes, edges) that hold any batch of ``batch_size`` graphs of this store, with the one spare node a
+        padded batch needs: the sums over the ``batch_size`` largest graphs."""
+        k = min(int(batch_size), self.num_graphs)
+        nn = np.sort(self.node_ptr[1:] - self.node_ptr[:-1])[::-1][:k].sum()
+        ne = np.sort(self.edge_ptr[1:] - self.edge_ptr[:-1])[::-1][:k].sum()
+        return int(nn) + 1, int(ne)
+
+    def collate(self, ids, out: Batch | None = None, capacity: tuple | None = None) -> Batch:
         """Mini-batch of the graphs ``ids`` (host sequence), in that order.
 
         ``out``: a batch returned earlier with the same number of graphs, nodes and edges; its tensors are
         overwritten in place (fixed-size point-cloud batches), so code captured into a HIP graph that reads them
-        sees the new batch on its next replay."""
+        sees the new batch on its next replay.
+
+        ``capacity`` = (nodes, edges), e.g. ``capacity_for(batch_size)``: a PADDED batch whose tensors have that
+        size whatever the graphs hold (molecules differ in size).  Rows past the real nodes are zero features that
+        belong to one extra graph (``batch`` value = number of graphs) and have no edges; entries past the real
+        edges are outside the sorted structure the layers use.  A model therefore returns one extra pooled row
+        (the last), and every real row equals the unpadded result.  A padded batch passed as ``out`` is refilled
+        by any ``ids`` of the same count that fit - the real sizes travel in the slot table on the device, so the
+        refill and the training step can be replayed from one HIP graph."""
         table = self.slot_table(ids)
         b = table.shape[1] - 1
         n, e = int(table[0, b]), int(table[1, b])
         dev = self.device
         if out is not None:
-            if (out.num_graphs, out.num_nodes, out.edge_index.size(1)) != (b, n, e) or out._parts is None:
-                raise ValueError("collate(out=...) needs a batch of identical size produced by this store")
+            if out._parts is None or out.num_graphs != b:
+                raise ValueError("collate(out=...) needs a batch with the same number of graphs produced by this store")
+            if out.capacity is not None:
+                if n >= out.capacity[0] or e > out.capacity[1]:
+                    raise ValueError(f"batch of {n} nodes / {e} edges exceeds the capacity {out.capacity}")
+            elif (out.num_nodes, out.edge_index.size(1)) != (n, e):
+                raise ValueError("collate(out=...) needs a batch of identical size (or a padded batch)")
             out._parts["slots"].copy_(torch.from_numpy(table), non_blocking=True)
-            self._launch(out._parts, b, n, e)
+            self._launch(out._parts, b, n, e, out.capacity)
             return out
+        if capacity is not None:
+            n_out, e_out = int(capacity[0]), int(capacity[1])
+            if n >= n_out or e > e_out:
+                raise ValueError(f"batch of {n} nodes / {e} edges exceeds the capacity {(n_out, e_out)}")
+            if not self.fused:
+                raise ValueError("padded batches need a store whose rows are never split (max degree <= 64)")
+        else:
+            n_out, e_out = n, e
         i32 = dict(dtype=torch.int32, device=dev)
-        ints = torch.empty(2 * (n + 1) + 5 * e, **i32)        # rowptr x2, col/eid x2, tpos
-        items = torch.empty((2, max(n, 1), 4), **i32)
-        o = 2 * (n + 1)
-        ea3 = torch.empty((3, e) + tuple(self.edge_attr.shape[1:]), dtype=self.edge_attr.dtype, device=dev)
+        ints = torch.empty(2 * (n_out + 1) + 5 * e_out + (b + 2), **i32)   # rowptr x2, col/eid x2, tpos, pool rowptr
+        items = torch.empty((2, max(n_out, 1), 4), **i32)
+        o = 2 * (n_out + 1)
+        ea3 = torch.empty((3, e_out) + tuple(self.edge_attr.shape[1:]), dtype=self.edge_attr.dtype, device=dev)
         parts = dict(
             slots=torch.from_numpy(table).to(dev, non_blocking=True),
-            x=torch.empty((n,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=dev),
-            pos=torch.empty((n,) + tuple(self.pos.shape[1:]), dtype=self.pos.dtype, device=dev) if self.pos is not None else None,
+            x=torch.empty((n_out,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=dev),
+            pos=torch.empty((n_out,) + tuple(self.pos.shape[1:]), dtype=self.pos.dtype, device=dev) if self.pos is not None else None,
             y=torch.empty((b,) + tuple(self.y.shape[1:]), dtype=self.y.dtype, device=dev) if self.y is not None else None,
-            batch=torch.empty(n, dtype=torch.int64, device=dev),
-            edge_index=torch.empty((2, e), dtype=torch.int64, device=dev),
+            batch=torch.empty(n_out, dtype=torch.int64, device=dev),
+            edge_index=torch.empty((2, e_out), dtype=torch.int64, device=dev),
             ea=ea3[0], ea_dst=ea3[1], ea_src=ea3[2],
-            rowptr_dst=ints[:n + 1], rowptr_src=ints[n + 1:o], items_dst=items[0], items_src=items[1])
+            rowptr_dst=ints[:n_out + 1], rowptr_src=ints[n_out + 1:o], items_dst=items[0], items_src=items[1],
+            pool_rowptr=ints[o + 5 * e_out:])
         for k, name in enumerate(("col_dst", "eid_dst", "col_src", "eid_src", "tpos")):
-            parts[name] = ints[o + k * e:o + (k + 1) * e]
-        self._launch(parts, b, n, e)
+            parts[name] = ints[o + k * e_out:o + (k + 1) * e_out]
+        self._launch(parts, b, n, e, capacity)
         res = Batch(parts["x"], parts["edge_index"], parts["batch"], parts["ea"], parts["y"], parts["pos"], b)
         res._parts = parts
+        res.capacity = (n_out, e_out) if capacity is not None else None
         if self.fused:
             views = []
             for sfx in ("dst", "src"):
                 c = CSR()
-                c.num_rows, c.num_cols, c.num_edges = n, n, e
+                c.num_rows, c.num_cols, c.num_edges = n_out, n_out, e_out
                 c.rowptr, c.col, c.eid = parts["rowptr_" + sfx], parts["col_" + sfx], parts["eid_" + sfx]
                 c.items, c.split = parts["items_" + sfx], None
-                c.n_items, c.n_parts, c.n_split = n, 0, 0
+                c.n_items, c.n_parts, c.n_split = n_out, 0, 0
                 views.append(c)
             g = MPGraph.from_parts(views[0], views[1], parts["tpos"])
             g.seed_edge_attr(parts["ea"], parts["ea_dst"], parts["ea_src"])
-            register_graph(parts["edge_index"], n, g)
-        if self._iota.numel() < n:
-            self._iota = torch.arange(max(n, 2 * self._iota.numel()), **i32)
-        register_pool(parts["batch"], b, parts["slots"][0], self._iota[:n])
+            register_graph(parts["edge_index"], n_out, g)
+        if self._iota.numel() < n_out:
+            self._iota = torch.arange(max(n_out, 2 * self._iota.numel()), **i32)
+        if capacity is not None:   # graphs 0 .. b-1 and the padding graph b
+            register_pool(parts["batch"], b + 1, parts["pool_rowptr"], self._iota[:n_out])
+        else:
+            register_pool(parts["batch"], b, parts["slots"][0], self._iota[:n])
         return res
 
-    def _launch(self, t: dict, b: int, n: int, e: int) -> None:
+    def _launch(self, t: dict, b: int, n: int, e: int, capacity=None) -> None:
         ga = self.graph_all
         row_bytes = lambda a: int(np.prod(a.shape[1:], dtype=np.int64)) * a.element_size()
         P = _lib.ptr
@@ -198,7 +233,10 @@ class GraphStore:
             ea=P(t["ea"]), ea_dst=P(t["ea_dst"]), ea_src=P(t["ea_src"]),
             rowptr_dst=P(t["rowptr_dst"]), col_dst=P(t["col_dst"]), eid_dst=P(t["eid_dst"]), items_dst=P(t["items_dst"]),
             rowptr_src=P(t["rowptr_src"]), col_src=P(t["col_src"]), eid_src=P(t["eid_src"]), items_src=P(t["items_src"]),
-            tpos=P(t["tpos"]))
+            tpos=P(t["tpos"]),
+            node_capacity=capacity[0] if capacity is not None else 0,
+            edge_capacity=capacity[1] if capacity is not None else 0,
+            pool_rowptr=P(t["pool_rowptr"]) if capacity is not None else None)
         _lib.check(_lib.load().mpnn_collate(ctypes.byref(d), _lib.stream_handle(self.device)), "mpnn_collate")
 
 

@@ -60,6 +60,16 @@ class FlatAdam:
                                       self.betas[0], self.betas[1], self.eps, _lib.stream_handle(self.flat.device)),
                    "mpnn_adam_step")
 
+    def state_snapshot(self):
+        """Copies of everything a step changes (parameters included); see state_restore."""
+        return [t.clone() for t in (self.flat, self.exp_avg, self.exp_avg_sq, self.state)]
+
+    def state_restore(self, snapshot) -> None:
+        """Puts a snapshot back in place (the tensors keep their addresses, so a recorded step stays valid)."""
+        with torch.no_grad():
+            for t, s0 in zip((self.flat, self.exp_avg, self.exp_avg_sq, self.state), snapshot):
+                t.copy_(s0)
+
     @property
     def steps_taken(self) -> int:
         return int(self.state[0].item())

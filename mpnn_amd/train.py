@@ -111,3 +111,52 @@ class CapturedStep:
     def replay(self) -> torch.Tensor:
         self.graph.replay()
         return self.loss
+
+
+class CapturedBatchStep:
+    """Mini-batch training where every full batch is one HIP-graph replay.
+
+    The graphs of a batch are written into ONE padded batch of fixed capacity (``GraphStore.collate(capacity=...)``:
+    molecules of any size fit, the real sizes travel on the device), and the step on that batch - zero_grad,
+    forward, ``loss_of(out, batch)``, backward, optimizer step - is recorded once.  ``train(ids)`` then costs the
+    slot-table copy, the two assembly kernels and one graph launch, whatever the number of kernels in the step.
+    ``loss_of`` defaults to the reference's choice, ``loss_fn(out[0], y[0])`` (training/train.py:22,74).  The model
+    output carries one extra last row (the padding graph); ``loss_of`` must not use it.  A batch with another
+    number of graphs (the short last batch of an epoch) runs eagerly through the same functions.
+    The optimizer must not read the device (``mpnn_amd.optim.FlatAdam``)."""
+
+    def __init__(self, model, optimizer, loss_fn, store, batch_size: int, features: str = "x", loss_of=None):
+        self.model, self.optimizer, self.loss_fn, self.store = model, optimizer, loss_fn, store
+        self.batch_size, self.features = int(batch_size), features
+        self.loss_of = loss_of or (lambda out, b: loss_fn(out[0], b.y[0]))
+        self.capacity = store.capacity_for(self.batch_size)
+        self.batch = None
+        self.captured = None
+
+    def _step(self, b):
+        self.optimizer.zero_grad()
+        out = self.model(getattr(b, self.features), b.edge_index, b.batch, b.edge_attr)
+        loss = self.loss_of(out, b)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def train(self, ids) -> torch.Tensor:
+        """One step on the graphs ``ids``; returns the loss as a device tensor (no host read)."""
+        self.model.train()
+        if len(ids) != self.batch_size:
+            return self._step(self.store.collate(ids))
+        if self.batch is None:
+            self.batch = self.store.collate(ids, capacity=self.capacity)
+            # the warm-up steps of the capture would train on this batch: record on a copy of the state
+            state = [p.detach().clone() for p in self.model.parameters()]
+            opt_state = self.optimizer.state_snapshot() if hasattr(self.optimizer, "state_snapshot") else None
+            self.captured = CapturedStep(lambda: self._step(self.batch), warmup=2)
+            with torch.no_grad():
+                for p, s0 in zip(self.model.parameters(), state):
+                    p.copy_(s0)
+            if opt_state is not None:
+                self.optimizer.state_restore(opt_state)
+        else:
+            self.store.collate(ids, out=self.batch)
+        return self.captured.replay()

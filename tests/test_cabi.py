@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_header_compiles_as_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "mpnn_amd.h"\nint main(void){return MPNN_ABI_VERSION == 6 ? 0 : 1;}\n')
+    src.write_text('#include "mpnn_amd.h"\nint main(void){return MPNN_ABI_VERSION == 7 ? 0 : 1;}\n')
     rc = os.system(f"gcc -std=c99 -Wall -Werror -I{ROOT}/include -c {src} -o {tmp_path}/t.o")
     assert rc == 0
 

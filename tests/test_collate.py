@@ -184,3 +184,98 @@ def test_collate_into_the_same_buffers_feeds_a_captured_step():
     with pytest.raises(ValueError):
         store.collate([0, 1], out=fixed)
     clear_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ids", [[5, 0, 39, 17, 17, 3], [7, 8, 9, 10, 11, 12]])
+def test_padded_collate_is_the_exact_batch_plus_padding(ids):
+    """capacity=(N, E): the first real rows / edge entries are bit for bit those of the exact batch, the rest is the
+    documented padding, and refilling the same buffers with other graphs gives what a fresh padded batch holds."""
+    from mpnn_amd.graph import clear_cache, graph_for
+    store, _ = _store_and_cpu("qm9", 40)
+    cap = store.capacity_for(len(ids))
+    exact = store.collate(ids)
+    n, e, b = exact.num_nodes, exact.edge_index.size(1), len(ids)
+    assert n < cap[0] and e <= cap[1]
+    ge = graph_for(exact.edge_index, n)
+    keep = {k: getattr(exact, k).clone() for k in ("x", "edge_index", "edge_attr", "batch", "y", "pos")}
+    keep.update(rowptr=ge.by_dst.rowptr.clone(), col=ge.by_dst.col.clone(), rowptr_t=ge.by_src.rowptr.clone(),
+                col_t=ge.by_src.col.clone(), tpos=ge.tpos.clone())
+    first = store.collate([1, 2, 3, 4, 6, 30], capacity=cap)       # other graphs first, then refilled in place
+    pad = store.collate(ids, out=first)
+    assert pad is first and pad.capacity == cap and pad.num_nodes == cap[0] and pad.edge_index.shape == (2, cap[1])
+    assert torch.equal(pad.x[:n], keep["x"]) and float(pad.x[n:].abs().sum()) == 0.0
+    assert torch.equal(pad.pos[:n], keep["pos"]) and float(pad.pos[n:].abs().sum()) == 0.0
+    assert torch.equal(pad.batch[:n], keep["batch"]) and bool((pad.batch[n:] == b).all())
+    assert torch.equal(pad.y, keep["y"])
+    assert torch.equal(pad.edge_index[:, :e], keep["edge_index"]) and bool((pad.edge_index[:, e:] == cap[0] - 1).all())
+    assert torch.equal(pad.edge_attr[:e], keep["edge_attr"]) and float(pad.edge_attr[e:].abs().sum()) == 0.0
+    g = graph_for(pad.edge_index, cap[0])
+    assert g.by_dst.n_items == cap[0] and g.by_dst.n_parts == 0
+    for view, rp, col in ((g.by_dst, "rowptr", "col"), (g.by_src, "rowptr_t", "col_t")):
+        assert torch.equal(view.rowptr[:n + 1], keep[rp]) and bool((view.rowptr[n:] == e).all())
+        assert torch.equal(view.col[:e], keep[col])
+        items = view.items[:cap[0]].cpu()
+        assert torch.equal(items[:, 0], torch.arange(cap[0], dtype=torch.int32))
+        assert torch.equal(items[:, 1], view.rowptr[:-1].cpu()) and torch.equal(items[:, 2], view.rowptr[1:].cpu())
+    assert torch.equal(g.tpos[:e], keep["tpos"])
+    seg = pad._parts["pool_rowptr"].cpu().tolist()
+    assert seg[:b + 1] == pad._parts["slots"][0].cpu().tolist() and seg[b] == n and seg[b + 1] == cap[0]
+    with pytest.raises(ValueError):
+        store.collate(ids, capacity=(n, e))                        # no room for the padding node
+    clear_cache()
+
+
+@pytest.mark.gpu
+def test_model_on_a_padded_batch_equals_the_exact_batch():
+    from mpnn_amd import MPNN_QM9
+    from mpnn_amd.graph import clear_cache
+    store, _ = _store_and_cpu("qm9", 64)
+    ids = list(range(10, 42))
+    torch.manual_seed(0)
+    model = MPNN_QM9(11, 4, 64, 19, num_layers=2, mode="sum").cuda()
+    res = []
+    for cap in (None, store.capacity_for(len(ids))):
+        b = store.collate(ids, capacity=cap)
+        model.zero_grad()
+        out = model(b.x, b.edge_index, b.batch, b.edge_attr)
+        assert out.size(0) == len(ids) + (cap is not None)
+        out = out[:len(ids)]
+        (out * out).sum().backward()
+        res.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}))
+    assert torch.equal(res[0][0], res[1][0])                       # real rows do not see the padding
+    for k in res[0][1]:                                            # sums over rows: other grouping, same terms + zeros
+        assert_close(res[1][1][k], res[0][1][k].double().cpu(), 1e-5, what=k)
+    clear_cache()
+
+
+@pytest.mark.gpu
+def test_captured_batch_step_trains_like_the_eager_loop():
+    """Molecule batches of varying size through one recorded step: same losses and weights as the eager loop
+    (to float32 rounding: the padded weight-gradient sums group their rows differently)."""
+    from mpnn_amd import MPNN_QM9
+    from mpnn_amd.optim import FlatAdam
+    from mpnn_amd.train import CapturedBatchStep
+    from mpnn_amd.graph import clear_cache
+    store, _ = _store_and_cpu("qm9", 50)
+    models, opts = [], []
+    for _ in range(2):
+        torch.manual_seed(7)
+        m = MPNN_QM9(11, 4, 32, 19, num_layers=2, mode="sum").cuda()
+        models.append(m)
+        opts.append(FlatAdam(m.parameters(), lr=1e-2))
+    loss_fn = F.mse_loss
+    fast = CapturedBatchStep(models[1], opts[1], loss_fn, store, batch_size=8)
+    batches = [list(range(0, 8)), list(range(20, 28)), [49, 3, 17, 5, 33, 8, 1, 40], [9, 9], list(range(30, 38))]
+    for ids in batches:
+        b = store.collate(ids)
+        opts[0].zero_grad()
+        le = loss_fn(models[0](b.x, b.edge_index, b.batch, b.edge_attr)[0], b.y[0])
+        le.backward()
+        opts[0].step()
+        lc = fast.train(ids)
+        assert_close(lc.reshape(1), le.detach().reshape(1).double().cpu(), 1e-4, what=f"loss of batch {ids[:2]}..")
+    assert opts[0].steps_taken == opts[1].steps_taken == len(batches)
+    for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+        assert_close(pb, pa.detach().double().cpu(), 1e-3, what="weights")
+    clear_cache()

@@ -150,3 +150,16 @@ def batch_and_replay():
 
 print(f"modelnet batch=32: assemble into fixed buffers + HIP-graph replay of the model step "
       f"{timeit(batch_and_replay, 60, 15):.3f} ms/step  (replay alone {timeit(cap.replay, 60, 15):.3f} ms)", flush=True)
+
+# ------------------------------------------------------------------------------------------------
+# molecule batches of varying size: one padded batch of fixed capacity, the step recorded once
+# ------------------------------------------------------------------------------------------------
+from mpnn_amd.train import CapturedBatchStep
+
+for bs in (128, 1024):
+    mq2 = MPNN_QM9(11, 4, 64, 19, num_layers=2, mode="sum").to(dev)
+    fast = CapturedBatchStep(mq2, FlatAdam(mq2.parameters(), lr=1e-3), F.mse_loss, q, batch_size=bs)
+    rq = np.random.default_rng(2)
+    t = timeit(lambda: fast.train(rq.permutation(q.num_graphs)[:bs]), 60, 15)
+    print(f"qm9 batch={bs}: padded batch (capacity {fast.capacity[0]} nodes / {fast.capacity[1]} edges) + HIP-graph "
+          f"replay of the model step {t:.3f} ms/step", flush=True)
