@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
   const bool act = c0 < a.H;
   const int cc = act ? c0 : 0;  // inactive lanes shadow column 0 and never store
 
-  const int ghalf = (grp << a.lpr_log2) >> 5, gsh = (grp << a.lpr_log2) & 31;
+  const int gfirst = grp << a.lpr_log2;   // first lane of this lane group
 
   float w[VEC][FE];
   load_edge_weights<T, VEC, FE>(a.We, a.fe, c0, act, w);
@@ -119,26 +119,28 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
         for (int u = 0; u < U; ++u) {
           const bool live = (j + u) < nb;
           const int jj = live ? (j + u) : (nb - 1);
-          float ev[FE], ce[VEC], bv[VEC];
+          float ev[FE];
 #pragma unroll
           for (int f = 0; f < FE; ++f) ev[f] = __shfl(ecur[f], jj, lpr);
-          edge_term<VEC, FE>(w, ev, ce);
-          RowIO<T, VEC>::unpack(braw[u], bv);
+          if (live) {   // slots past the chunk's end only cost the (cached) load: their lanes sit out the arithmetic
+            float ce[VEC], bv[VEC];
+            edge_term<VEC, FE>(w, ev, ce);
+            RowIO<T, VEC>::unpack(braw[u], bv);
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            float m = relu_f((ar[v] + bv[v]) + ce[v]);
-            m = live ? m : 0.f;
-            acc[v] += m;
-            if (TRAIN) {
-              const bool pos = m > 0.f;
-              cn[v] += pos ? 1 : 0;
-              if (TRAIN == 2) {
-                // The wave's vote as two 32-bit halves; the group's bits start at bit `gsh` of half `ghalf`
-                // (higher bits belong to other groups; the reader tests bit `lig` only).  Lane j + u of the
-                // group keeps the words of this edge.
-                const unsigned long long vote = __ballot(pos);
-                const uint32_t word = (ghalf ? (uint32_t)(vote >> 32) : (uint32_t)vote) >> gsh;
-                mb[v] = (lig == j + u) ? word : mb[v];
+            for (int v = 0; v < VEC; ++v) {
+              const float m = relu_f((ar[v] + bv[v]) + ce[v]);
+              acc[v] += m;
+              if (TRAIN) {
+                const bool pos = m > 0.f;
+                cn[v] += pos ? 1 : 0;
+                if (TRAIN == 2) {
+                  // The wave's vote shifted down to the group's first lane (higher bits belong to other groups;
+                  // the reader tests bit `lig` only; lanes that sit out vote 0).  Lane j + u of the group keeps
+                  // the words of this edge.
+                  const unsigned long long vote = __ballot(pos);
+                  const uint32_t word = (uint32_t)(vote >> gfirst);
+                  mb[v] = (lig == j + u) ? word : mb[v];
+                }
               }
             }
           }
