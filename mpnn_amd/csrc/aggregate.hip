@@ -17,6 +17,8 @@
 //     round the group with ds_bpermute; U row gathers per lane are kept in flight.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "edgeops.h"
 
 #ifndef MPNN_FWD_WAVES
@@ -42,7 +44,8 @@ struct FwdArgs {
   float* cnt;
   float* part_out;
   float* part_cnt;
-  uint32_t* maskbits;  // optional [E][VEC] words: bit `lig` of word v = (message column lig*VEC+v of this edge > 0)
+  uint32_t* maskbits;  // optional [E][mpnn_mask_words] words: bit `lig` of word v = (message column lig*VEC+v of this
+                       // edge > 0); 16-bit words, two per 32-bit word, when a row takes at most 16 lanes of 8 columns
   int H; int lpr_log2;
 };
 
@@ -149,11 +152,18 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
       if (TRAIN == 2 && VEC % 4 == 0) {
         // one coalesced store per chunk: lane lig writes the VEC words of edge base + lig
         if (lig < nb) {
-          uint32_t* mp = a.maskbits + (int64_t)(base + lig) * VEC;
+          if (VEC == 8 && lpr <= 16) {   // 16 lanes per row: two 16-bit words share a 32-bit one (16 bytes per edge)
+            uint32_t* mp = a.maskbits + (int64_t)(base + lig) * 4;
+            u32x4 w4 = {(mb[0] & 0xffffu) | (mb[1] << 16), (mb[2] & 0xffffu) | (mb[3] << 16),
+                        (mb[4 % VEC] & 0xffffu) | (mb[5 % VEC] << 16), (mb[6 % VEC] & 0xffffu) | (mb[7 % VEC] << 16)};
+            __builtin_nontemporal_store(w4, reinterpret_cast<u32x4*>(mp));
+          } else {
+            uint32_t* mp = a.maskbits + (int64_t)(base + lig) * VEC;
 #pragma unroll
-          for (int v = 0; v < VEC; v += 4) {
-            u32x4 w4 = {mb[v], mb[v + 1], mb[v + 2], mb[v + 3]};
-            __builtin_nontemporal_store(w4, reinterpret_cast<u32x4*>(mp + v));
+            for (int v = 0; v < VEC; v += 4) {
+              u32x4 w4 = {mb[v], mb[v + 1], mb[v + 2], mb[v + 3]};
+              __builtin_nontemporal_store(w4, reinterpret_cast<u32x4*>(mp + v));
+            }
           }
         }
       }
@@ -298,7 +308,7 @@ struct BwdMaskArgs {
   int H; int lpr_log2;
 };
 
-template <typename T, int VEC, int FE, bool RTFE, int U>
+template <typename T, int VEC, int FE, bool RTFE, int U, bool PACK>
 __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a) {
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
@@ -344,14 +354,21 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a)
           const int d = __shfl(cur, jj, lpr);
           const int pp = __shfl(curp, jj, lpr);
           RowIO<T, VEC>::load(a.G + (int64_t)d * a.ldG + cc, gv[u]);
-          const uint32_t* mp = a.maskbits + (int64_t)pp * VEC;
+          if constexpr (PACK) {   // 16-bit words, two per 32-bit word (see the forward kernel); compile-time: a
+                                  // load under a run-time branch would make the compiler wait for every load in flight
+            const u32x4 w = NT_LOAD(reinterpret_cast<const u32x4*>(a.maskbits + (int64_t)pp * 4));
+            mw[u][0] = w.x; mw[u][1 % VEC] = w.x >> 16; mw[u][2 % VEC] = w.y; mw[u][3 % VEC] = w.y >> 16;
+            mw[u][4 % VEC] = w.z; mw[u][5 % VEC] = w.z >> 16; mw[u][6 % VEC] = w.w; mw[u][7 % VEC] = w.w >> 16;
+          } else {
+            const uint32_t* mp = a.maskbits + (int64_t)pp * VEC;
 #pragma unroll
-          for (int v = 0; v < VEC; v += 4) {
-            const u32x4 w = NT_LOAD(reinterpret_cast<const u32x4*>(mp + v));
-            mw[u][v] = w.x;
-            if (v + 1 < VEC) mw[u][v + 1] = w.y;
-            if (v + 2 < VEC) mw[u][v + 2] = w.z;
-            if (v + 3 < VEC) mw[u][v + 3] = w.w;
+            for (int v = 0; v < VEC; v += 4) {
+              const u32x4 w = NT_LOAD(reinterpret_cast<const u32x4*>(mp + v));
+              mw[u][v] = w.x;
+              if (v + 1 < VEC) mw[u][v + 1] = w.y;
+              if (v + 2 < VEC) mw[u][v + 2] = w.z;
+              if (v + 3 < VEC) mw[u][v + 3] = w.w;
+            }
           }
           load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(base + jj), a.fe, ev[u]);
         }
@@ -569,9 +586,14 @@ static int32_t run_bwd_masked(const void* G, int64_t ldG, const uint32_t* maskbi
   const int tile = (1 << g.lpr_log2) * VEC;
   const int fe_t = Fe == 4 ? 4 : (Fe == 1 ? 1 : kMaxFe);
   const size_t lds = (size_t)(kBlock / 64) * tile * fe_t * sizeof(float);
-  if (Fe == 4) k_agg_bwd_src_masked<T, VEC, 4, false, U><<<grid, kBlock, lds, stream>>>(a);
-  else if (Fe == 1) k_agg_bwd_src_masked<T, VEC, 1, false, U><<<grid, kBlock, lds, stream>>>(a);
-  else k_agg_bwd_src_masked<T, VEC, kMaxFe, true, U><<<grid, kBlock, lds, stream>>>(a);
+  auto go = [&](auto pack) {
+    constexpr bool PACK = decltype(pack)::value;
+    if (Fe == 4) k_agg_bwd_src_masked<T, VEC, 4, false, U, PACK><<<grid, kBlock, lds, stream>>>(a);
+    else if (Fe == 1) k_agg_bwd_src_masked<T, VEC, 1, false, U, PACK><<<grid, kBlock, lds, stream>>>(a);
+    else k_agg_bwd_src_masked<T, VEC, kMaxFe, true, U, PACK><<<grid, kBlock, lds, stream>>>(a);
+  };
+  if (VEC == 8 && g.lpr_log2 <= 4) go(std::true_type{});
+  else go(std::false_type{});
   MPNN_LAUNCH_CHECK("k_agg_bwd_src_masked");
   if (n_split > 0) {
     int32_t rc = launch_reduce_split<T, VEC>(part_gB, split, n_split, static_cast<T*>(gB), ldgB, H, g, stream);
@@ -664,7 +686,7 @@ int32_t mpnn_mask_words(int32_t H, int32_t dtype) {
   if (H < 1 || (dtype != MPNN_F32 && dtype != MPNN_BF16)) return 0;
   const Geometry g = geometry(H, dtype, true);
   if (g.vec == 1 || g.tiles != 1 || g.lpr_log2 > 5) return 0;
-  return g.vec;
+  return (g.vec == 8 && g.lpr_log2 <= 4) ? 4 : g.vec;   // rows of at most 16 lanes pack two 16-bit words per word
 }
 
 int64_t mpnn_bwd_scratch_floats(int32_t H, int32_t Fe) {

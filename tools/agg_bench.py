@@ -25,9 +25,11 @@ if order:   # experiment: edge order inside each row of the two sorted structure
 chunk = int(os.environ.get("AGG_CHUNK", "0"))
 g = MPGraph(d["edge_index"], n, chunk=chunk) if chunk else MPGraph(d["edge_index"], n)
 print("chunk", chunk or "default", "items", g.by_dst.n_items, "parts", g.by_dst.n_parts, "| transpose items", g.by_src.n_items, "parts", g.by_src.n_parts)
-ab = torch.randn(n, 2 * H, device=dev, requires_grad=True)
-we = torch.randn(H, 4, device=dev, requires_grad=True)
-r = torch.randn(n, H, device=dev)
+dt = torch.bfloat16 if os.environ.get("AGG_DTYPE") == "bf16" else torch.float32
+ab = torch.randn(n, 2 * H, device=dev).to(dt).requires_grad_(True)
+we = torch.randn(H, 4, device=dev).to(dt).requires_grad_(True)
+r = torch.randn(n, H, device=dev).to(dt)
+d["edge_attr"] = d["edge_attr"].to(dt)
 for it in range(3):
     ops.EVENT_SINK = []
     for _ in range(5):
@@ -39,7 +41,7 @@ for it in range(3):
 t = {}
 for name, a, b in ev:
     t.setdefault(name, []).append(a.elapsed_time(b))
-s = 4
+s = 2 if dt == torch.bfloat16 else 4
 for k, v in t.items():
     ms = sorted(v)[len(v) // 2]
     if k == "aggregate_fwd":
