@@ -471,8 +471,10 @@ __global__ void __launch_bounds__(kBlock) k_segment_mean_bwd(const T* __restrict
 // ---------------------------------------------------------------------------------------
 // Host-side dispatch
 // ---------------------------------------------------------------------------------------
-// Row gathers kept in flight per lane by the forward kernel: 4, or 2 when a lane owns 8 columns (bfloat16 rows),
-// where 4 would push the kernel past its register budget and into scratch.  MPNN_FWD_U=2|4 overrides (tuning).
+// Row gathers kept in flight per lane by the forward kernel: 4.  With 8 columns per lane (bfloat16 rows) that
+// spills some 40-60 registers at 4 waves per SIMD, and is still faster than 2 gathers without spills or 4 gathers
+// at 3 waves (5.9 vs 6.8 ms inference, 8.0 vs 8.4 ms training on the 100 M-edge graph): the pass needs both the
+// occupancy and the loads in flight.  MPNN_FWD_U=2|4 overrides (tuning).
 static int fwd_unroll(int vec) {
   static int forced = [] {
     const char* e = getenv("MPNN_FWD_U");
@@ -480,7 +482,7 @@ static int fwd_unroll(int vec) {
     return (v == 2 || v == 4) ? v : 0;
   }();
   if (forced) return forced;
-  return vec >= 8 ? 2 : 4;
+  return 4;
 }
 
 template <typename T, int VEC, int TRAIN, int U>
