@@ -18,10 +18,13 @@ _SCRATCH = {}
 
 
 def _scratch(n: int, device) -> torch.Tensor:
-    buf = _SCRATCH.get(device)
+    """Partial-tile scratch of the weight-gradient products, one buffer per (device, stream): calls on one stream
+    reuse it in stream order, calls on different streams never share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(n, dtype=torch.float32, device=device)
-        _SCRATCH[device] = buf
+        _SCRATCH[key] = buf
     return buf
 
 
