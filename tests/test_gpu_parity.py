@@ -138,7 +138,9 @@ def test_aggregate_fwd_bwd_fp32(n, e, H, Fe, skew, dev):
     assert_close(got[2], want[2], RTOL32, what="grad We")
 
 
-@pytest.mark.parametrize("n,e,H,Fe", [(300, 3000, 64, 4), (200, 4000, 128, 4), (100, 700, 24, 2)])
+# H <= 128: packed 16-bit mask words; H = 256: 32 lanes per row, one 32-bit word per column group; H = 8: one lane
+@pytest.mark.parametrize("n,e,H,Fe", [(300, 3000, 64, 4), (200, 4000, 128, 4), (100, 700, 24, 2), (150, 2500, 256, 4),
+                                      (120, 1500, 8, 1)])
 def test_aggregate_fwd_bwd_bf16(n, e, H, Fe, dev):
     got, want, _ = _aggregate_case(dev, n, e, H, Fe, seed=3, dtype=torch.bfloat16)
     assert_close(got[0].float(), want[0], RTOL16, what="aggregate out (bf16)")
