@@ -21,51 +21,82 @@ namespace mpnn {
 constexpr int kKnnMax = 32;        // neighbours tracked per point
 constexpr int kKnnMaxPoints = 8192;  // points per cloud held in LDS (3 floats each)
 
+constexpr int kKnnQueries = 64;                  // query points per block: one per lane
+constexpr int kKnnParts = kBlock / kKnnQueries;  // waves of a block; each scans its share of the candidates
+
+// Sorted insert without branches: the candidate takes the place of the first strictly farther entry (so entries
+// that are already listed stay ahead at equal distance) and everything from there on moves down one place.
+template <int K>
+__device__ __forceinline__ void knn_insert(float (&bd)[K], int (&bj)[K], float cd, int cj) {
+  bool placed = false;
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    placed = placed || cd < bd[t];
+    const float od = bd[t];
+    const int oj = bj[t];
+    bd[t] = placed ? cd : od;
+    bj[t] = placed ? cj : oj;
+    cd = placed ? od : cd;
+    cj = placed ? oj : cj;
+  }
+}
+
 // K = neighbours tracked per point (>= k), a compile-time size so that the candidate list lives in registers.
+// A block serves 64 query points of one cloud.  Its 4 waves each scan a quarter of the cloud's points (ascending
+// index ranges) for all 64 queries, lane = query; the lists of waves 1..3 then pass through LDS and wave 0 merges
+// them into its own in wave order.  Because every list is sorted by (distance, index) and a later wave's points
+// all have higher indices, the merged list is the one a single ascending scan would have produced.
 template <int K>
 __global__ void __launch_bounds__(kBlock) k_knn(const float* __restrict__ pos, int points, int k,
                                                 int64_t* __restrict__ edge_index, int64_t num_edges,
                                                 float* __restrict__ dist, unsigned int* __restrict__ cloud_max) {
-  extern __shared__ float cloud[];   // x[points], y[points], z[points]
-  __shared__ float s_max[kBlock];
+  extern __shared__ float cloud[];   // x[points], y[points], z[points], then the lists of waves 1..3
   const int c = blockIdx.x;
   const int64_t base = (int64_t)c * points;
   float* xs = cloud;
   float* ys = cloud + points;
   float* zs = cloud + 2 * points;
+  float* list_d = cloud + 3 * points;                                                  // [parts - 1][K][64]
+  int* list_j = reinterpret_cast<int*>(list_d + (kKnnParts - 1) * K * kKnnQueries);    // same shape
   for (int j = threadIdx.x; j < points; j += kBlock) {
     xs[j] = pos[(base + j) * 3];
     ys[j] = pos[(base + j) * 3 + 1];
     zs[j] = pos[(base + j) * 3 + 2];
   }
   __syncthreads();
-  const int i = blockIdx.y * kBlock + threadIdx.x;
+  const int q = threadIdx.x & (kKnnQueries - 1), part = threadIdx.x / kKnnQueries;
+  const int i = blockIdx.y * kKnnQueries + q;
   const int iq = i < points ? i : points - 1;   // surplus lanes shadow the last point and store nothing
   float bd[K];
   int bj[K];
 #pragma unroll
   for (int t = 0; t < K; ++t) { bd[t] = INFINITY; bj[t] = 0; }
   const float xi = xs[iq], yi = ys[iq], zi = zs[iq];
-  for (int j = 0; j < points; ++j) {
+  const int share = (points + kKnnParts - 1) / kKnnParts;
+  const int j0 = part * share, j1 = j0 + share < points ? j0 + share : points;
+  for (int j = j0; j < j1; ++j) {
     // plain operators on purpose: the contract(off) pragma above governs them (it does not reach into the
     // bodies of intrinsic wrappers defined in headers)
     const float dx = xi - xs[j], dy = yi - ys[j], dz = zi - zs[j];
     float cd = (dx * dx + dy * dy) + dz * dz;
     cd = j == iq ? INFINITY : cd;
     if (!__any(cd < bd[K - 1])) continue;   // wave-uniform: nobody has a use for this candidate
-    int cj = j;
-    // Sorted insert without branches: the candidate takes the place of the first strictly farther entry (so
-    // earlier, lower indices stay ahead at equal distance) and everything from there on moves down one place.
-    bool placed = false;
+    knn_insert<K>(bd, bj, cd, j);
+  }
+  if (part > 0) {
 #pragma unroll
     for (int t = 0; t < K; ++t) {
-      placed = placed || cd < bd[t];
-      const float od = bd[t];
-      const int oj = bj[t];
-      bd[t] = placed ? cd : od;
-      bj[t] = placed ? cj : oj;
-      cd = placed ? od : cd;
-      cj = placed ? oj : cj;
+      list_d[((part - 1) * K + t) * kKnnQueries + q] = bd[t];
+      list_j[((part - 1) * K + t) * kKnnQueries + q] = bj[t];
+    }
+  }
+  __syncthreads();
+  if (part > 0) return;   // no barrier below
+  for (int p = 0; p < kKnnParts - 1; ++p) {
+    for (int t = 0; t < K; ++t) {
+      const float cd = list_d[(p * K + t) * kKnnQueries + q];
+      if (!__any(cd < bd[K - 1])) break;   // the list ascends: nothing further in it can enter any lane's list
+      knn_insert<K>(bd, bj, cd, list_j[(p * K + t) * kKnnQueries + q]);
     }
   }
   float far = 0.f;
@@ -82,14 +113,11 @@ __global__ void __launch_bounds__(kBlock) k_knn(const float* __restrict__ pos, i
       }
     }
   }
-  s_max[threadIdx.x] = far;
-  __syncthreads();
-  for (int off = kBlock / 2; off > 0; off >>= 1) {
-    if (threadIdx.x < off) s_max[threadIdx.x] = fmaxf(s_max[threadIdx.x], s_max[threadIdx.x + off]);
-    __syncthreads();
-  }
-  // distances are non-negative, so their bit patterns order like unsigned integers; max is order-independent
-  if (threadIdx.x == 0) atomicMax(cloud_max + c, __float_as_uint(s_max[0]));
+  // the largest edge length of the wave's queries (xor tree over the 64 lanes); distances are non-negative, so
+  // their bit patterns order like unsigned integers, and a maximum does not depend on the order of its operands
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) far = fmaxf(far, __shfl_xor(far, off));
+  if (q == 0) atomicMax(cloud_max + c, __float_as_uint(far));
 }
 
 __global__ void __launch_bounds__(kBlock) k_knn_normalise(const float* __restrict__ dist,
@@ -119,19 +147,23 @@ extern "C" int32_t mpnn_knn_graph(const float* pos, int32_t num_clouds, int32_t 
   float* dist = workspace;
   unsigned int* cloud_max = reinterpret_cast<unsigned int*>(workspace + num_edges);
   MPNN_HIP_CHECK(hipMemsetAsync(cloud_max, 0, (size_t)num_clouds * sizeof(unsigned int), stream));
-  const size_t lds = (size_t)3 * points * sizeof(float);
-  dim3 grid(num_clouds, (points + kBlock - 1) / kBlock);
-  auto launch = [&](auto kern) -> int32_t {
+  dim3 grid(num_clouds, (points + kKnnQueries - 1) / kKnnQueries);
+  auto launch = [&](auto kern, int K) -> int32_t {
+    const size_t lds = ((size_t)3 * points + (size_t)2 * (kKnnParts - 1) * K * kKnnQueries) * sizeof(float);
     if (lds > 48 * 1024)
       MPNN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     kern<<<grid, kBlock, lds, stream>>>(pos, points, k, edge_index, num_edges, dist, cloud_max);
     return MPNN_OK;
   };
   int32_t rc;
-  if (k <= 8) rc = launch(k_knn<8>);
-  else if (k <= 16) rc = launch(k_knn<16>);
-  else if (k <= 24) rc = launch(k_knn<24>);
-  else rc = launch(k_knn<32>);
+  if (k <= 4) rc = launch(k_knn<4>, 4);          // list lengths in steps of 4: the insert costs K steps per candidate
+  else if (k <= 8) rc = launch(k_knn<8>, 8);
+  else if (k <= 12) rc = launch(k_knn<12>, 12);
+  else if (k <= 16) rc = launch(k_knn<16>, 16);
+  else if (k <= 20) rc = launch(k_knn<20>, 20);
+  else if (k <= 24) rc = launch(k_knn<24>, 24);
+  else if (k <= 28) rc = launch(k_knn<28>, 28);
+  else rc = launch(k_knn<32>, 32);
   if (rc != MPNN_OK) return rc;
   MPNN_LAUNCH_CHECK("k_knn");
   k_knn_normalise<<<(unsigned)((num_edges + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dist, cloud_max, (int64_t)points * k,

@@ -17,7 +17,8 @@ def test_oracle_knn_known_answer():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("clouds,points,k", [(1, 2, 1), (3, 50, 7), (4, 300, 20), (32, 1024, 20), (2, 1500, 32)])
+@pytest.mark.parametrize("clouds,points,k", [(1, 2, 1), (1, 3, 2), (3, 50, 7), (4, 300, 20), (32, 1024, 20), (2, 1500, 32),
+                                             (1, 8192, 24)])
 def test_knn_kernel_is_bit_exact(clouds, points, k):
     from mpnn_amd.knn import knn_graph
     g = torch.Generator().manual_seed(points)
@@ -25,6 +26,8 @@ def test_knn_kernel_is_bit_exact(clouds, points, k):
     if points >= 50:
         pos[1] = pos[0]              # coincident points: zero distance, tie on the next neighbour
         pos[7] = pos[5]
+        pos[points // 2 + 1] = pos[3]    # ties between points that different waves of a block scan
+        pos[points - 1] = pos[3]
     want_ei, want_ea = ro.knn_graph(pos, clouds, k)
     ei, ea = knn_graph(pos.cuda(), clouds, k)
     assert torch.equal(ei.cpu(), want_ei)
