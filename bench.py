@@ -233,6 +233,15 @@ def main():
     else:
         graph_build_ms = None
         pg = PartitionedGraph(d["edge_index"], n_total, rank, world)
+        # every rank generated the graph on its own: the halo exchanges assume identical partitions, so compare
+        # them (a mismatch would otherwise show up as a hang inside a collective)
+        sig = torch.tensor([pg.n_pad, sum(pg.bounds), int(d["edge_index"].sum().item() % (1 << 40))],
+                           dtype=torch.int64, device=dev if args.backend == "nccl" else "cpu")
+        lo_sig, hi_sig = sig.clone(), sig.clone()
+        dist.all_reduce(lo_sig, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_sig, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo_sig, hi_sig):
+            raise SystemExit(f"rank {rank}: the ranks built different graphs or partitions ({sig.tolist()})")
         x = pg.local_rows(d["x"]).to(dtype).clone().requires_grad_(not args.first_layer)
         ea = pg.local_edges(d["edge_attr"]).to(dtype).clone()
         n_rows_fwd, n_rows_bwd, e_local = pg.n_local, world * pg.n_pad, pg.edge_ids.numel()
