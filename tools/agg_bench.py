@@ -13,6 +13,12 @@ kind = sys.argv[3] if len(sys.argv) > 3 else "powerlaw"
 n, e = int(4_000_000 * scale), int(100_000_000 * scale)
 if kind == "powerlaw":
     d = synth.powerlaw(dev, 0, n, e, 8, 4)
+elif kind == "regular":   # every row has exactly AGG_DEG incoming edges from uniform random sources
+    deg = int(os.environ.get("AGG_DEG", "24")); e = n * deg
+    dst = torch.arange(n, device=dev).repeat_interleave(deg)
+    pm = torch.randperm(e, device=dev)
+    d = {"edge_index": torch.stack([torch.randint(0, n, (e,), device=dev), dst])[:, pm].contiguous(),
+         "edge_attr": torch.rand(e, 4, device=dev)}
 else:
     d = {"edge_index": torch.randint(0, n, (2, e), device=dev), "edge_attr": torch.rand(e, 4, device=dev)}
 order = os.environ.get("AGG_ORDER", "")
