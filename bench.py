@@ -157,7 +157,8 @@ def main():
     ap.add_argument("--workload", default="powerlaw", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="sum", choices=["sum", "cat"])
     ap.add_argument("--layer", default="mpnn", choices=["mpnn", "egnn"],
-                    help="egnn: EGNNLayer (message pass + coordinate update in one edge pass; single GPU)")
+                    help="egnn: EGNNLayer (message pass + coordinate update in one edge pass; one GPU, or data "
+                         "parallel with --workload qm9 | modelnet)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,8 +206,9 @@ def main():
     F_in, H, Fe = d["x"].size(1), cfg["H"], d["edge_attr"].size(1)
     torch.manual_seed(0)
     if args.layer == "egnn":
-        if world > 1:
-            raise SystemExit("--layer egnn runs on one GPU (batched workloads scale by data parallelism)")
+        if world > 1 and not data_parallel:
+            raise SystemExit("--layer egnn on several GPUs needs a batched workload (--workload qm9 | modelnet): "
+                             "those scale by data parallelism; the partitioned single-graph path is MPNN only")
         from mpnn_amd import EGNNLayer
         layer = EGNNLayer(F_in, Fe, H).to(dev, dtype)
         pos = d["pos"].float() if "pos" in d else torch.randn(n_total, 3, device=dev)
