@@ -20,6 +20,9 @@ from . import _lib
 CHUNK = 64
 CHUNK_MAX = 1024
 MAX_PARTS = 256
+# Edge lists of at least this many edges get their sorted views laid out in work-item order by graph_for()
+# (see MPGraph, ``row_order``).
+ITEM_ORDER_MIN_EDGES = 1 << 22
 
 
 def default_chunk(num_edges: int) -> int:
@@ -34,19 +37,27 @@ class CSR:
     """One sorted view of the edge list (see mpnn_csr_build / mpnn_items_build)."""
 
     __slots__ = ("num_rows", "num_cols", "num_edges", "rowptr", "col", "eid", "items", "split",
-                 "n_items", "n_parts", "n_split")
+                 "n_items", "n_parts", "n_split", "order")
 
     def degree(self) -> torch.Tensor:
-        return self.rowptr[1:] - self.rowptr[:-1]
+        """Edges per row, indexed by row id."""
+        deg = self.rowptr[1:] - self.rowptr[:-1]
+        order = getattr(self, "order", None)
+        if order is None:
+            return deg
+        out = torch.empty_like(deg)
+        out[order] = deg          # rowptr is indexed by storage position; order[j] = row stored at position j
+        return out
 
 
 def _build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: int,
-               chunk: int, max_parts: int) -> CSR:
+               chunk: int, max_parts: int, item_order: bool = False) -> CSR:
     lib = _lib.load()
     dev = key.device
     E = key.numel()
     stream = _lib.stream_handle(dev)
     csr = CSR()
+    csr.order = None
     csr.num_rows, csr.num_cols, csr.num_edges = num_rows, num_cols, E
     csr.rowptr = torch.empty(num_rows + 1, dtype=torch.int32, device=dev)
     csr.col = torch.empty(E, dtype=torch.int32, device=dev)
@@ -59,7 +70,16 @@ def _build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: 
     _lib.check(lib.mpnn_csr_build(_lib.ptr(key), _lib.ptr(other), E, num_rows, num_cols, _lib.ptr(csr.rowptr),
                                   _lib.ptr(csr.col), _lib.ptr(csr.eid), _lib.ptr(status), _lib.ptr(ws), ws.numel(),
                                   stream), "mpnn_csr_build")
+    if item_order:
+        _rows_into_item_order(csr, status, chunk)
+    return csr, _build_items(csr, chunk, max_parts, status, ws)
 
+
+def _build_items(csr: CSR, chunk: int, max_parts: int, status: torch.Tensor, ws: torch.Tensor):
+    lib = _lib.load()
+    dev = csr.rowptr.device
+    num_rows, E = csr.num_rows, csr.num_edges
+    stream = _lib.stream_handle(dev)
     items_cap = num_rows + E // chunk + 1
     split_cap = E // (chunk + 1) + 1
     csr.items = torch.empty((items_cap, 4), dtype=torch.int32, device=dev)
@@ -73,7 +93,27 @@ def _build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: 
     _lib.check(lib.mpnn_items_build(_lib.ptr(csr.rowptr), num_rows, chunk, max_parts, _lib.ptr(csr.items),
                                     items_cap, _lib.ptr(csr.split), split_cap, _lib.ptr(meta), _lib.ptr(ws),
                                     ws.numel(), stream), "mpnn_items_build")
-    return csr, torch.cat([meta[:4], status[:1]])
+    return torch.cat([meta[:4], status[:1]])
+
+
+def _rows_into_item_order(csr: CSR, status: torch.Tensor, chunk: int) -> None:
+    """Moves the rows of a freshly sorted view into the order in which mpnn_items_build lists them: split rows
+    first in row order, then descending degree, row order among equals.  Edges keep their order inside a row."""
+    if int(status[0]) != 0:   # the arrays are not trustworthy: report it before indexing with them
+        raise IndexError(f"edge_index holds node ids outside [0, {csr.num_rows}) x [0, {csr.num_cols})")
+    n, e = csr.num_rows, csr.num_edges
+    deg = csr.rowptr[1:] - csr.rowptr[:-1]
+    sort_key = torch.where(deg > chunk, torch.zeros_like(deg), 1 + chunk - deg)
+    order = torch.argsort(sort_key, stable=True)
+    deg_o = deg[order].long()
+    newptr = torch.zeros(n + 1, dtype=torch.int64, device=deg.device)
+    torch.cumsum(deg_o, 0, out=newptr[1:])
+    shift = csr.rowptr[:-1][order].long() - newptr[:-1]          # old minus new position, per stored row
+    perm = torch.repeat_interleave(shift, deg_o, output_size=e)
+    perm += torch.arange(e, dtype=torch.int64, device=perm.device)
+    csr.col, csr.eid = csr.col[perm], csr.eid[perm]
+    csr.rowptr = newptr.to(torch.int32)
+    csr.order = order
 
 
 def _finish(csrs, pending) -> None:
@@ -85,6 +125,15 @@ def _finish(csrs, pending) -> None:
         if h[3] != 0:
             raise _lib.MpnnError("mpnn_items_build overflowed its output capacity")
         csr.n_items, csr.n_parts, csr.n_split = h[0], h[1], h[2]
+
+
+def _rows_to_ids(csr: CSR) -> None:
+    """After an items build over storage positions: the work items and split records name rows by id again."""
+    order = csr.order
+    if csr.n_items:
+        csr.items[:csr.n_items, 0] = order[csr.items[:csr.n_items, 0].long()].to(torch.int32)
+    if csr.n_split:
+        csr.split[:csr.n_split, 0] = order[csr.split[:csr.n_split, 0].long()].to(torch.int32)
 
 
 def build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: int,
@@ -101,10 +150,17 @@ class MPGraph:
     ``edge_index`` is int64 ``[2, E]``, row 0 = source, row 1 = target, unsorted, duplicates
     allowed (PyG convention used by the reference, models/layers.py:38,110).
     ``num_dst`` / ``num_src`` differ only for a rank-local piece of a partitioned graph.
+
+    ``row_order="items"`` stores the rows of both views in the order the work items list them instead of by row
+    id: the kernels walk the views through the items' (row, first, last) records only, so the index lists, the
+    sorted edge attributes and the relu-mask words of consecutive work items then lie next to each other in memory
+    (one sequential stream per array instead of a scattered piece per row).  ``rowptr`` is then indexed by storage
+    position (``CSR.order[j]`` = id of the row stored at position j); edges inside a row keep their order, so every
+    result is bit-identical to the ``"natural"`` layout.
     """
 
     def __init__(self, edge_index: torch.Tensor, num_dst: int, num_src: int | None = None,
-                 chunk: int | None = None, max_parts: int = MAX_PARTS):
+                 chunk: int | None = None, max_parts: int = MAX_PARTS, row_order: str = "natural"):
         _lib.require_device(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
             raise ValueError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
@@ -115,9 +171,15 @@ class MPGraph:
         dst = edge_index[1].contiguous()
         self.num_dst, self.num_src, self.num_edges = int(num_dst), int(num_src), src.numel()
         chunk = default_chunk(self.num_edges) if chunk is None else chunk
-        self.by_dst, p1 = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts)
-        self.by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts)
+        if row_order not in ("natural", "items"):
+            raise ValueError(f"row_order must be 'natural' or 'items', got {row_order!r}")
+        by_items = row_order == "items" and self.num_edges > 0
+        self.by_dst, p1 = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts, by_items)
+        self.by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, by_items)
         _finish([self.by_dst, self.by_src], [p1, p2])
+        if by_items:
+            _rows_to_ids(self.by_dst)
+            _rows_to_ids(self.by_src)
         self._ea_key = None
         self._ea_sorted = None
         self._scratch = {}
@@ -183,6 +245,13 @@ class MPGraph:
         return buf
 
 
+def make_graph(edge_index: torch.Tensor, num_dst: int, num_src: int | None = None) -> MPGraph:
+    """MPGraph in the layout graph_for() uses for an edge list of this size: rows in work-item order once the
+    list is long enough for the scattered per-row pieces to cost more than the one-off reordering."""
+    big = edge_index.dim() == 2 and edge_index.size(1) >= ITEM_ORDER_MIN_EDGES
+    return MPGraph(edge_index, num_dst, num_src, row_order="items" if big else "natural")
+
+
 _CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
 _CACHE_SIZE = 8
 
@@ -201,7 +270,7 @@ def graph_for(edge_index: torch.Tensor, num_nodes: int) -> MPGraph:
     if hit is not None:
         _CACHE.move_to_end(key)
         return hit[1]
-    g = MPGraph(edge_index, num_nodes)
+    g = make_graph(edge_index, num_nodes)
     _CACHE[key] = (edge_index, g)
     while len(_CACHE) > _CACHE_SIZE:
         _CACHE.popitem(last=False)

@@ -19,7 +19,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import dense, layer_fn, ops
-from .graph import MPGraph
+from .graph import make_graph
 from .layers import MPNNLayerCat, MPNNLayerSum, _update
 
 
@@ -49,7 +49,7 @@ class PartitionedGraph:
     produces: rank q's rows occupy [q * n_pad, q * n_pad + (bounds[q+1] - bounds[q])).
     """
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, graph_factory=MPGraph):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, rank: int, world: int, graph_factory=make_graph):
         src, dst = edge_index[0], edge_index[1]
         self.rank, self.world, self.num_nodes = rank, world, num_nodes
         self.bounds = dst_range_bounds(dst, num_nodes, world)

@@ -82,6 +82,51 @@ def test_work_items_of_a_large_edge_list_use_longer_pieces(dev):
     assert graph.by_dst.n_parts == parts and parts > 0
 
 
+def test_rows_in_work_item_order_give_identical_results(dev):
+    """row_order="items" only moves whole rows inside the sorted views: the work items become one ascending run
+    over the edge arrays, and the fused operator returns bit-identical outputs and gradients."""
+    from mpnn_amd import synth
+    from mpnn_amd.graph import MPGraph
+    from mpnn_amd.ops import aggregate_fused
+    n, e, H = 20000, 600000, 64
+    d = synth.powerlaw(dev, 3, n, e, 8, 4)
+    ei = d["edge_index"]
+    g_nat = MPGraph(ei, n, chunk=64)
+    g_it = MPGraph(ei, n, chunk=64, row_order="items")
+    for a, b in ((g_nat.by_dst, g_it.by_dst), (g_nat.by_src, g_it.by_src)):
+        assert b.n_items == a.n_items and b.n_split == a.n_split
+        assert torch.equal(a.degree(), b.degree())
+        items = b.items[:b.n_items].cpu()
+        assert int(items[0, 1]) == 0 and int(items[-1, 2]) == e and torch.equal(items[1:, 1], items[:-1, 2])
+        # same rows, same pieces
+        listing = lambda it: sorted(zip(it[:, 0].tolist(), (it[:, 2] - it[:, 1]).tolist(), it[:, 3].tolist()))
+        assert listing(items) == listing(a.items[:a.n_items].cpu())
+        # every row holds the same (neighbour, edge id) sequence
+        order = b.order.cpu()
+        for j in (0, 1, n // 2, n - 1):
+            row = int(order[j])
+            got = slice(int(b.rowptr[j]), int(b.rowptr[j + 1]))
+            want = slice(int(a.rowptr[row]), int(a.rowptr[row + 1]))
+            assert torch.equal(b.col[got], a.col[want]) and torch.equal(b.eid[got], a.eid[want])
+    assert g_it.by_dst.n_split > 0      # the hubs of this graph are cut into pieces
+    gen = torch.Generator(device=dev).manual_seed(1)
+    ab = torch.randn(n, 2 * H, generator=gen, device=dev)
+    we = torch.randn(H, 4, generator=gen, device=dev)
+    r = torch.randn(n, H, generator=gen, device=dev)
+    res = []
+    for g in (g_nat, g_it):
+        ab_, we_ = ab.clone().requires_grad_(True), we.clone().requires_grad_(True)
+        out = aggregate_fused(ab_, d["edge_attr"], we_, g)
+        out.backward(r)
+        res.append((out.detach(), ab_.grad, we_.grad))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    bad = ei.clone()
+    bad[1, 5] = n
+    with pytest.raises(IndexError):
+        MPGraph(bad, n, row_order="items")
+
+
 def test_out_of_range_edge_raises(dev):
     from mpnn_amd.graph import MPGraph
     ei = torch.tensor([[0, 1, 9], [1, 2, 0]], dtype=torch.int64, device=dev)
