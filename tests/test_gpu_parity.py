@@ -121,6 +121,19 @@ def test_rows_in_work_item_order_give_identical_results(dev):
         res.append((out.detach(), ab_.grad, we_.grad))
     for x, y in zip(*res):
         assert torch.equal(x, y)
+    # the EGNN edge passes walk the same structures
+    from mpnn_amd import egnn_aggregate
+    pos = torch.rand(n, 3, generator=gen, device=dev) * 2 - 1
+    wp = torch.randn(H, generator=gen, device=dev) / H
+    rp = torch.randn(n, 3, generator=gen, device=dev)
+    res = []
+    for g in (g_nat, g_it):
+        leaves = [t.clone().requires_grad_(True) for t in (ab[:, :H].contiguous(), ab[:, H:].contiguous(), we, pos, wp)]
+        aggr, pos_out = egnn_aggregate(leaves[0], leaves[1], d["edge_attr"], leaves[2], leaves[3], leaves[4], g)
+        ((aggr * r).sum() + (pos_out * rp).sum()).backward()
+        res.append([aggr.detach(), pos_out.detach()] + [t.grad for t in leaves])
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
     bad = ei.clone()
     bad[1, 5] = n
     with pytest.raises(IndexError):
