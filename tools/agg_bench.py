@@ -29,7 +29,7 @@ if order:   # experiment: edge order inside each row of the two sorted structure
         perm = torch.argsort(ei[1], stable=True); perm = perm[torch.argsort(ei[0][perm], stable=True)]
     d["edge_index"] = ei[:, perm].contiguous(); d["edge_attr"] = d["edge_attr"][perm].contiguous()
 chunk = int(os.environ.get("AGG_CHUNK", "0"))
-g = MPGraph(d["edge_index"], n, chunk=chunk) if chunk else MPGraph(d["edge_index"], n)
+g = MPGraph(d["edge_index"], n, chunk=chunk or None, row_order=os.environ.get("AGG_ROWS", "items"))
 print("chunk", chunk or "default", "items", g.by_dst.n_items, "parts", g.by_dst.n_parts, "| transpose items", g.by_src.n_items, "parts", g.by_src.n_parts)
 dt = torch.bfloat16 if os.environ.get("AGG_DTYPE") == "bf16" else torch.float32
 ab = torch.randn(n, 2 * H, device=dev).to(dt).requires_grad_(True)
