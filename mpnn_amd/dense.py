@@ -46,6 +46,14 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t if t.stride(-1) == 1 and t.dim() == 2 else t.contiguous()
 
 
+def _ld(t) -> int:
+    """Leading dimension of a matrix with unit column stride, 0 for None.  A single-row matrix may carry any
+    stride(0) (torch keeps e.g. 1 after ``.t().contiguous()`` of a one-column matrix): its row length serves."""
+    if t is None:
+        return 0
+    return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+
+
 def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=None, out2=None) -> torch.Tensor:
     """act(x1 @ w1^T [+ x2 @ w2^T]); maskI > 0 selects the entries of xI that are used.
 
@@ -63,13 +71,13 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=N
     k2 = x2.size(1) if x2 is not None else 0
     wimg = _wsplit(lib.mpnn_gemm_nt_scratch_bytes(m, k1, k2), x1.device)
     _lib.check(lib.mpnn_gemm_nt_f32(
-        _lib.ptr(x1), x1.stride(0), _lib.ptr(mask1), mask1.stride(0) if mask1 is not None else 0, _lib.ptr(w1),
-        w1.stride(0), k1,
-        _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(mask2),
-        mask2.stride(0) if mask2 is not None else 0, _lib.ptr(w2), w2.stride(0) if w2 is not None else 0,
+        _lib.ptr(x1), _ld(x1), _lib.ptr(mask1), _ld(mask1), _lib.ptr(w1),
+        _ld(w1), k1,
+        _lib.ptr(x2), _ld(x2), _lib.ptr(mask2),
+        _ld(mask2), _lib.ptr(w2), _ld(w2),
         x2.size(1) if x2 is not None else 0,
-        _lib.ptr(y), y.stride(0), _lib.ptr(emul), emul.stride(0) if emul is not None else 0, _lib.ptr(out2),
-        out2.stride(0) if out2 is not None else 0, n, m, 1 if relu else 0, _lib.ptr(wimg),
+        _lib.ptr(y), _ld(y), _lib.ptr(emul), _ld(emul), _lib.ptr(out2),
+        _ld(out2), n, m, 1 if relu else 0, _lib.ptr(wimg),
         _lib.stream_handle(x1.device)),
         "mpnn_gemm_nt_f32")
     return y
@@ -96,11 +104,11 @@ def gemm_nt_bf16(x1, w1, x2=None, w2=None, relu=False, emul=None, out2=None) -> 
     m = w1.size(0)
     y = torch.empty((n, m), dtype=torch.bfloat16, device=x1.device)
     _lib.check(lib.mpnn_gemm_nt_bf16(
-        _lib.ptr(x1), x1.stride(0), _lib.ptr(w1), w1.stride(0), k1,
-        _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(w2), w2.stride(0) if w2 is not None else 0,
+        _lib.ptr(x1), _ld(x1), _lib.ptr(w1), _ld(w1), k1,
+        _lib.ptr(x2), _ld(x2), _lib.ptr(w2), _ld(w2),
         x2.size(1) if x2 is not None else 0,
-        _lib.ptr(y), y.stride(0), _lib.ptr(emul), emul.stride(0) if emul is not None else 0, _lib.ptr(out2),
-        out2.stride(0) if out2 is not None else 0, n, m, 1 if relu else 0, _lib.stream_handle(x1.device)),
+        _lib.ptr(y), _ld(y), _lib.ptr(emul), _ld(emul), _lib.ptr(out2),
+        _ld(out2), n, m, 1 if relu else 0, _lib.stream_handle(x1.device)),
         "mpnn_gemm_nt_bf16")
     return y
 
@@ -116,9 +124,9 @@ def gemm_tn_bf16(g, x, mask=None, out=None, g_out=None, x2=None) -> torch.Tensor
         out = torch.empty((m, k + k2), dtype=torch.bfloat16, device=g.device)
     scratch = _scratch(lib.mpnn_gemm_tn_bf16_scratch_floats(n, m, k + k2), g.device)
     _lib.check(lib.mpnn_gemm_tn_bf16(
-        _lib.ptr(g), g.stride(0), _lib.ptr(mask), mask.stride(0) if mask is not None else 0, _lib.ptr(x),
-        x.stride(0), _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(out), out.stride(0),
-        _lib.ptr(scratch), _lib.ptr(g_out), g_out.stride(0) if g_out is not None else 0, n, m, k, k2,
+        _lib.ptr(g), _ld(g), _lib.ptr(mask), _ld(mask), _lib.ptr(x),
+        _ld(x), _lib.ptr(x2), _ld(x2), _lib.ptr(out), _ld(out),
+        _lib.ptr(scratch), _lib.ptr(g_out), _ld(g_out), n, m, k, k2,
         _lib.stream_handle(g.device)), "mpnn_gemm_tn_bf16")
     return out
 
@@ -137,9 +145,9 @@ def gemm_tn(g, x, mask=None, out=None, g_out=None, x2=None) -> torch.Tensor:
     mask = _rows(mask) if mask is not None else None
     scratch = _scratch(lib.mpnn_gemm_tn_scratch_floats(n, m, k + k2), g.device)
     _lib.check(lib.mpnn_gemm_tn_f32(
-        _lib.ptr(g), g.stride(0), _lib.ptr(mask), mask.stride(0) if mask is not None else 0, _lib.ptr(x),
-        x.stride(0), _lib.ptr(x2), x2.stride(0) if x2 is not None else 0, _lib.ptr(out), out.stride(0),
-        _lib.ptr(scratch), _lib.ptr(g_out), g_out.stride(0) if g_out is not None else 0, n, m, k, k2,
+        _lib.ptr(g), _ld(g), _lib.ptr(mask), _ld(mask), _lib.ptr(x),
+        _ld(x), _lib.ptr(x2), _ld(x2), _lib.ptr(out), _ld(out),
+        _lib.ptr(scratch), _lib.ptr(g_out), _ld(g_out), n, m, k, k2,
         _lib.stream_handle(g.device)), "mpnn_gemm_tn_f32")
     return out
 

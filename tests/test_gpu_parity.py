@@ -272,6 +272,31 @@ def test_layer_golden(case, mode, dev):
 
 
 # --------------------------------------------------------------------------- pooling and models
+@pytest.mark.parametrize("mode", ["sum", "cat"])
+@pytest.mark.parametrize("n,e,f,h,fe", [(300, 2000, 1, 16, 3), (1, 4, 5, 8, 2), (2, 0, 1, 4, 1)])
+def test_layer_degenerate_widths(mode, n, e, f, h, fe, dev):
+    """One input feature, a single node, no edges: matrices with a single row or column keep whatever stride torch
+    left them, which must not reach the kernels as a leading dimension."""
+    from mpnn_amd import MPNNLayerCat, MPNNLayerSum
+    gen = torch.Generator().manual_seed(n + e)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)])
+    x, ea, r = torch.randn(n, f, generator=gen), torch.rand(e, fe, generator=gen), torch.randn(n, h, generator=gen)
+    torch.manual_seed(3)
+    layer = (MPNNLayerSum if mode == "sum" else MPNNLayerCat)(f, fe, h)
+    ws = [p.detach().clone().requires_grad_(True) for p in layer.parameters()]
+    xw = x.clone().requires_grad_(True)
+    want = (O.layer_sum if mode == "sum" else O.layer_cat)(xw, ei, ea, *ws)
+    (want * r).sum().backward()
+    layer = layer.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg, ei.to(dev), ea.to(dev))
+    (out * r.to(dev)).sum().backward()
+    assert_close(out, want.detach(), RTOL32, what="out")
+    assert_close(xg.grad, xw.grad, RTOL32, what="gx")
+    for p, w in zip(layer.parameters(), ws):
+        assert_close(p.grad, w.grad, RTOL32, what="gW")
+
+
 def test_global_mean_pool_golden(dev):
     from mpnn_amd import global_mean_pool
     g = load_golden("pool")

@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU: GEMM entry points against float64 products, the fused edge operator against a
-float64 statement of it, over odd shapes and both row orders.  Usage: python tools/fuzz_parity.py [seed] [cases]"""
+float64 statement of it and whole layers against the oracle in float64, over odd shapes and both row orders.  Usage: python tools/fuzz_parity.py [seed] [cases]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -23,6 +23,8 @@ def close(got, want, rtol, what):
 
 
 worst = 0.0
+worst_layer = 0.0
+boundary_cases = 0
 for c in range(cases):
     # ---- GEMMs
     n, k1, m = R(1, 3000), R(1, 300), R(1, 300)
@@ -73,6 +75,44 @@ for c in range(cases):
         for name, got, want in (("out", out, want_out), ("gAB", gl[0].grad, leaves[0].grad), ("gWe", gl[1].grad, leaves[1].grad)):
             if want.numel():
                 worst = max(worst, close(got, want.detach(), 2e-5, f"case {c} {order} n={nn} e={e} H={H} Fe={Fe} {name}"))
+    # ---- whole layers (fused autograd node when the shapes allow it) against the oracle run in float64
+    from mpnn_amd import MPNNLayerCat, MPNNLayerSum
+    from oracle import reference_oracle as O
+    F_in, Hl = R(1, 40) * R(1, 4), R(1, 32) * 4
+    nl, el = R(2, 2500), R(0, 20000)
+    eil = torch.stack([torch.randint(0, nl, (el,), generator=g), torch.randint(0, nl, (el,), generator=g)])
+    xl, eal, rl = torch.randn(nl, F_in, generator=g), torch.rand(el, Fe, generator=g), torch.randn(nl, Hl, generator=g)
+    mode = "sum" if R(0, 1) else "cat"
+    torch.manual_seed(seed * 1000 + c)
+    layer = (MPNNLayerSum if mode == "sum" else MPNNLayerCat)(F_in, Fe, Hl)
+    ws = [p.detach().double().requires_grad_(True) for p in layer.parameters()]
+    xw = xl.double().requires_grad_(True)
+    want = (O.layer_sum if mode == "sum" else O.layer_cat)(xw, eil, eal.double(), *ws)
+    (want * rl.double()).sum().backward()
+    layer = layer.to(dev)
+    xg = xl.to(dev).requires_grad_(True)
+    out = layer(xg, eil.to(dev), eal.to(dev))
+    (out * rl.to(dev)).sum().backward()
+    pairs = [("out", out, want), ("gx", xg.grad, xw.grad)] + [(f"gW{i}", p.grad, w.grad) for i, (p, w) in enumerate(zip(layer.parameters(), ws))]
+    # A pre-activation within float32 rounding of zero may fall on the other side of the relu on the GPU: the
+    # output hardly changes, the gradients of that row do.  Such cases are counted, not compared.
+    with torch.no_grad():
+        if mode == "sum":
+            ab_ = xw @ ws[0].t()
+            pre_m = ab_[eil[1], :Hl] + ab_[eil[0], Hl:] + eal.double() @ ws[1].t()
+            w_out = ws[2]
+        else:
+            pre_m = torch.cat([xw[eil[1]], xw[eil[0]], eal.double()], 1) @ ws[0].t()
+            w_out = ws[1]
+        aggr_ = torch.zeros(nl, Hl, dtype=torch.float64).index_add_(0, eil[1], pre_m.clamp_min(0))
+        pre_u = torch.cat([xw, aggr_], 1) @ w_out.t()
+        scale_m = float(pre_m.abs().max()) if el else 1.0
+        near = int((pre_m.abs() < 1.5e-7 * scale_m).sum()) + int((pre_u.abs() < 1.5e-7 * float(pre_u.abs().max())).sum())
+    if near:
+        boundary_cases += 1
+        pairs = pairs[:1]
+    for name, got, wnt in pairs:
+        worst_layer = max(worst_layer, close(got, wnt.detach(), 1e-5, f"case {c} layer {mode} n={nl} e={el} F={F_in} H={Hl} Fe={Fe} {name}"))
     if c % 10 == 9:
-        print(f"{c + 1} cases ok (worst edge-operator error so far, relative to the largest entry: {worst:.2e})", flush=True)
+        print(f"{c + 1} cases ok (worst edge-operator error so far, relative to the largest entry: {worst:.2e}; layers {worst_layer:.2e}, {boundary_cases} with a pre-activation at the relu boundary: outputs only)", flush=True)
 print("fuzz ok")
