@@ -78,7 +78,7 @@ for c in range(cases):
     # ---- whole layers (fused autograd node when the shapes allow it) against the oracle run in float64
     from mpnn_amd import MPNNLayerCat, MPNNLayerSum
     from oracle import reference_oracle as O
-    F_in, Hl = R(1, 40) * R(1, 4), R(1, 32) * 4
+    F_in, Hl = (R(1, 40) * R(1, 4), R(1, 32) * 4) if R(0, 2) else (R(1, 150), R(1, 130))   # a third with odd widths
     nl, el = R(2, 2500), R(0, 20000)
     eil = torch.stack([torch.randint(0, nl, (el,), generator=g), torch.randint(0, nl, (el,), generator=g)])
     xl, eal, rl = torch.randn(nl, F_in, generator=g), torch.rand(el, Fe, generator=g), torch.randn(nl, Hl, generator=g)
