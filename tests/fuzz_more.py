@@ -1,6 +1,6 @@
 """Randomised parity sweep, second part: k-NN graphs and mean pooling (bit-exact / float64), the EGNN edge operator
 against the oracle in float64, bfloat16 layers against the float32 oracle on bf16-rounded inputs.
-Usage: python tools/fuzz_more.py [seed] [cases]"""
+Usage: python tests/fuzz_more.py [seed] [cases]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

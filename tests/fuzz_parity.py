@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU: GEMM entry points against float64 products, the fused edge operator against a
-float64 statement of it and whole layers against the oracle in float64, over odd shapes and both row orders.  Usage: python tools/fuzz_parity.py [seed] [cases]"""
+float64 statement of it and whole layers against the oracle in float64, over odd shapes and both row orders.  Usage: python tests/fuzz_parity.py [seed] [cases]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
