@@ -67,13 +67,16 @@ for c in range(cases):
     msg = torch.relu(a_[ei[1]] + b_[ei[0]] + ea.double() @ leaves[1].t())
     want_out = torch.zeros(nn, H, dtype=torch.float64).index_add_(0, ei[1], msg)
     (want_out * r.double()).sum().backward()
+    # a message whose pre-activation is zero to float32 rounding may fall on the other side of the relu on the GPU
+    pre = (a_[ei[1]] + b_[ei[0]] + ea.double() @ leaves[1].t()).detach()
+    at_kink = bool(e) and int((pre.abs() < 1.5e-7 * float(pre.abs().max())).sum()) > 0
     for order in ("natural", "items"):
         graph = MPGraph(ei.to(dev), nn, chunk=R(1, 3) * 16, row_order=order)
         gl = [t.clone().to(dev).requires_grad_(True) for t in (ab, we)]
         out = aggregate_fused(gl[0], ea.to(dev), gl[1], graph)
         (out * r.to(dev)).sum().backward()
         for name, got, want in (("out", out, want_out), ("gAB", gl[0].grad, leaves[0].grad), ("gWe", gl[1].grad, leaves[1].grad)):
-            if want.numel():
+            if want.numel() and not (at_kink and name != "out"):
                 worst = max(worst, close(got, want.detach(), 2e-5, f"case {c} {order} n={nn} e={e} H={H} Fe={Fe} {name}"))
     # ---- whole layers (fused autograd node when the shapes allow it) against the oracle run in float64
     from mpnn_amd import MPNNLayerCat, MPNNLayerSum
