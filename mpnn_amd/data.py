@@ -129,8 +129,9 @@ class GraphStore:
         return slot_table(self.node_ptr, self.edge_ptr, ids)
 
     def capacity_for(self, batch_size: int) -> tuple:
-        """(nodes, edges) that hold any batch of ``batch_size`` graphs of this store, with the one spare node a
-        padded batch needs: the sums over the ``batch_size`` largest graphs."""
+        """(nodes, edges) that hold any batch of ``batch_size`` DISTINCT graphs of this store (what a loader draws),
+        with the one spare node a padded batch needs: the sums over the ``batch_size`` largest graphs.  A batch
+        that repeats graphs may need more; collate() refuses a batch that does not fit."""
         k = min(int(batch_size), self.num_graphs)
         nn = np.sort(self.node_ptr[1:] - self.node_ptr[:-1])[::-1][:k].sum()
         ne = np.sort(self.edge_ptr[1:] - self.edge_ptr[:-1])[::-1][:k].sum()
