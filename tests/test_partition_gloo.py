@@ -43,8 +43,7 @@ def make_problem(mode):
 
 
 def _worker(rank, world, port, mode, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port, out_dir)
     try:
         from mpnn_amd.partition import PartitionedGraph, allreduce_gradients, partitioned_model
         torch.set_num_threads(1)
@@ -62,6 +61,14 @@ def _worker(rank, world, port, mode, out_dir):
                    os.path.join(out_dir, f"rank{rank}.pt"))
     finally:
         dist.destroy_process_group()
+
+
+def _init(rank, world, port, out_dir):
+    """File rendezvous in the test's own directory: no fixed port that another process could take between the
+    moment it was found free and the moment rank 0 binds it.  (MASTER_* stay set for code that reads them.)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", init_method=f"file://{os.path.join(out_dir, 'rendezvous')}", rank=rank,
+                            world_size=world)
 
 
 def _free_port():
@@ -105,8 +112,7 @@ def test_bounds_match_oracle_for_many_world_sizes():
 
 
 def _dp_worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port, out_dir)
     try:
         from mpnn_amd.partition import allreduce_gradients
         torch.manual_seed(0)
@@ -136,8 +142,7 @@ def test_data_parallel_gradient_allreduce(tmp_path):
 # through gloo (device tensors staged through the host); only the RCCL transport itself is not covered
 # ---------------------------------------------------------------------------------------------
 def _gpu_worker(rank, world, port, mode, out_dir):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port, out_dir)
     try:
         from mpnn_amd.partition import PartitionedGraph, allreduce_gradients, partitioned_model
         dev = torch.device("cuda:0")
