@@ -108,3 +108,26 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "reference_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_drop_in_package_mirrors_the_reference_imports():
+    """`integration/models` stands in for the reference's `models` package: the same three import forms the
+    experiments and main.py use (models/__init__.py:1-2, experiments/*_exp.py) resolve to the HIP-backed classes."""
+    import importlib
+    import sys
+    import mpnn_amd
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "models" or k.startswith("models.")}
+    sys.path.insert(0, os.path.join(ROOT, "integration"))
+    try:
+        models = importlib.import_module("models")
+        assert models.MPNN is mpnn_amd.MPNN and models.MPNNLayerCat is mpnn_amd.MPNNLayerCat
+        assert models.MPNNLayerSum is mpnn_amd.MPNNLayerSum
+        mp = importlib.import_module("models.mpnn")
+        assert mp.MPNN_QM9 is mpnn_amd.MPNN_QM9 and mp.MPNN_ModelNet is mpnn_amd.MPNN_ModelNet
+        layers = importlib.import_module("models.layers")
+        assert layers.MPNNLayerSum is mpnn_amd.MPNNLayerSum
+    finally:
+        sys.path.remove(os.path.join(ROOT, "integration"))
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
