@@ -3,7 +3,7 @@
 The reference downloads Flickr / QM9 / ModelNet through torch_geometric on first use; there is no network here,
 so these classes serve SYNTHETIC data of the same shapes (mpnn_amd.synth) from GPU memory through the same
 methods: ``FlickrDataset.get_data/get_split``, ``QM9Dataset.get_loader/get_full_graphs``,
-``ModelNetDataset.get_loaders/get_full_graphs``.  Loaders are GraphLoaders (device-side batch assembly); the
+``ModelNetDataset.get_loaders/get_full_graphs``, ``S3DISDataset.get_train_data/get_test_data``.  Loaders are GraphLoaders (device-side batch assembly); the
 full-graph variants return one Batch holding every graph of a split, as ``Batch.from_data_list`` does in the
 reference (data/dataset.py:120-124, 225-227).
 """
@@ -100,3 +100,44 @@ class ModelNetDataset:
     def get_full_graphs(self):
         return (self.train_store.collate(np.arange(self.train_store.num_graphs)),
                 self.test_store.collate(np.arange(self.test_store.num_graphs)))
+
+
+class S3DISDataset:
+    """data/dataset.py:147-178: indoor scans cut into blocks of ``points`` points with 6 features (colour and
+    normalised position) and one of 13 classes per point; ``get_train_data`` / ``get_test_data`` return the blocks
+    of the training areas / of ``test_area``.  The reference's experiment for it is a stub
+    (experiments/s3dis_exp.py:13-22) and the blocks carry no edges there; here every block comes with its k-NN
+    graph and normalised-distance edge feature, ready for the layers.  Per-point labels are ``store.point_y``; the
+    per-block ``y`` is the block's most frequent class."""
+
+    NUM_CLASSES = 13
+
+    def __init__(self, root: str = "data/S3DIS", transform=None, test_area=1, device="cuda", seed: int = 0,
+                 train_blocks: int = 64, test_blocks: int = 16, points: int = 4096, k: int = 16):
+        self.test_area = test_area
+        self._args = (device, seed, points, k)
+        self._sizes = {"train": train_blocks, "test": test_blocks}
+        self._stores = {}
+
+    def _make(self, split: str) -> GraphStore:
+        if split not in self._stores:
+            device, seed, points, k = self._args
+            blocks = self._sizes[split]
+            g = torch.Generator(device=device).manual_seed(seed + (0 if split == "train" else 1000 + int(self.test_area)))
+            pos = torch.rand(blocks * points, 3, generator=g, device=device) * 2 - 1
+            x = torch.cat([torch.rand(blocks * points, 3, generator=g, device=device), (pos + 1) / 2], dim=1)
+            edge_index, edge_attr = knn_graph(pos, blocks, k)
+            point_y = torch.randint(0, self.NUM_CLASSES, (blocks * points,), generator=g, device=device)
+            y = torch.mode(point_y.view(blocks, points), dim=1).values
+            node_ptr = np.arange(blocks + 1, dtype=np.int64) * points
+            edge_ptr = np.arange(blocks + 1, dtype=np.int64) * points * k
+            store = GraphStore(x, edge_index, edge_attr, node_ptr, edge_ptr, y=y, pos=pos)
+            store.point_y = point_y
+            self._stores[split] = store
+        return self._stores[split]
+
+    def get_train_data(self) -> GraphStore:
+        return self._make("train")
+
+    def get_test_data(self) -> GraphStore:
+        return self._make("test")

@@ -10,6 +10,8 @@ def test_wrappers_expose_the_reference_method_names():
     assert {"get_data", "get_split"} <= set(dir(datasets.FlickrDataset))
     assert {"get_loader", "get_full_graphs", "get_data"} <= set(dir(datasets.QM9Dataset))
     assert {"get_loaders", "get_full_graphs"} <= set(dir(datasets.ModelNetDataset))
+    assert {"get_train_data", "get_test_data"} <= set(dir(datasets.S3DISDataset))
+    assert list(inspect.signature(datasets.S3DISDataset.__init__).parameters)[:4] == ["self", "root", "transform", "test_area"]
     assert list(inspect.signature(datasets.QM9Dataset.get_loader).parameters)[:3] == ["self", "batch_size", "shuffle"]
     assert list(inspect.signature(datasets.ModelNetDataset.get_loaders).parameters) == ["self", "batch_size", "shuffle"]
     assert datasets._split_sizes(1001) == (800, 100, 101)
@@ -71,3 +73,18 @@ def test_modelnet_and_flickr_stand_ins():
     for _ in range(5):
         l1 = t.train(d)
     assert l1 < l0 and 0.0 <= t.test(d) <= 1.0
+
+
+@pytest.mark.gpu
+def test_s3dis_stand_in_feeds_a_layer():
+    from mpnn_amd import MPNNLayerSum
+    from mpnn_amd.datasets import S3DISDataset
+    ds = S3DISDataset(train_blocks=3, test_blocks=2, points=256, k=8)
+    train, test = ds.get_train_data(), ds.get_test_data()
+    assert train.num_graphs == 3 and test.num_graphs == 2 and ds.get_train_data() is train
+    assert train.x.shape == (3 * 256, 6) and train.point_y.shape == (3 * 256,) and int(train.point_y.max()) < 13
+    batch = train.collate([2, 0])
+    assert batch.x.shape == (512, 6) and batch.edge_index.shape == (2, 512 * 8) and batch.edge_attr.shape == (512 * 8, 1)
+    layer = MPNNLayerSum(6, 1, 16).cuda()
+    out = layer(batch.x, batch.edge_index, batch.edge_attr)
+    assert out.shape == (512, 16) and bool(torch.isfinite(out).all())
