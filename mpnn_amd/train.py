@@ -6,11 +6,17 @@ of scoring only graph 0 of a batch (``loss_fn(out[0], data.y[0])``, training/tra
 anything with the attributes the reference reads (x / pos, edge_index, batch, edge_attr, y, train_mask,
 test_mask): a ``mpnn_amd.data.Batch`` or a plain namespace.
 
+``Train_QM9``, ``Train_QM9_FB``, ``Train_Flickr``, ``Train_ModelNet`` and ``Train_ModelNet_FB`` are the reference's
+epoch loops (training/train.py:88-195) with their signatures: mini-batch loaders or one full batch per split,
+per-epoch report lines, and with ``benchmark=True`` only the timing summary plus one evaluation at the end.
+
 ``CapturedStep`` records one whole training step (forward, loss, backward, optimizer) into a HIP graph when the
 step's tensors keep their addresses and shapes - a full-graph trainer, or fixed-size point-cloud batches written
 into the same buffers - and replays it with no per-launch host work.
 """
 from __future__ import annotations
+
+import time
 
 import torch
 import torch.nn.functional as F
@@ -160,3 +166,71 @@ class CapturedBatchStep:
         else:
             self.store.collate(ids, out=self.batch)
         return self.captured.replay()
+
+
+def _batches(data, device):
+    """A loader yields batches; a single full batch (the reference's _FB variants) is its own one-element epoch."""
+    for b in (data if hasattr(data, "__iter__") and not hasattr(data, "edge_index") else (data,)):
+        b.to(device)
+        yield b
+
+
+def _epochs(trainer, train_data, report_data, final_data, device, epochs, benchmark, report_name, final_name):
+    """The loop all five reference functions share: train on every batch of ``train_data`` per epoch; without
+    ``benchmark`` evaluate ``report_data`` after each epoch and print one line; with it, time the epochs, print
+    the time and epochs per second, then evaluate ``final_data`` once."""
+    start = time.time()
+    for epoch in range(epochs):
+        loss = sum(trainer.train(b) for b in _batches(train_data, device))
+        if not benchmark and report_data is not None:
+            value = sum(trainer.test(b) for b in _batches(report_data, device))
+            print(f"Epoch {epoch + 1:03d} | Loss: {loss:.4f} | {report_name}: {value:.4f}")
+    if benchmark:
+        elapsed = time.time() - start
+        print(f"Training Time: {elapsed:.4f} seconds")
+        print(f"Troughput: {epochs / elapsed:.3f} epoch/sec")     # the reference's spelling (training/train.py:109)
+        if final_data is not None:
+            value = sum(trainer.test(b) for b in _batches(final_data, device))
+            print(f"{final_name}: {value:.4f}")
+
+
+def Train_QM9(model, data_loader, optimizer, loss_fn, device, epochs=3, benchmark=False):
+    """training/train.py:88-114: (train, val, test) loaders; test loss per epoch, validation loss after a benchmark."""
+    train_loader, val_loader, test_loader = data_loader
+    _epochs(Trainer_QM9(model, optimizer, loss_fn, device), train_loader, test_loader, val_loader, device, epochs,
+            benchmark, "Test Loss", "Validation Loss")
+
+
+def Train_QM9_FB(model, data_set, optimizer, loss_fn, device, epochs=3, benchmark=False):
+    """training/train.py:116-136: one full batch per split."""
+    train_set, val_set, test_set = data_set
+    _epochs(Trainer_QM9(model, optimizer, loss_fn, device), train_set, test_set, val_set, device, epochs, benchmark,
+            "Test Loss", "Validation Loss")
+
+
+def Train_Flickr(model, data, optimizer, loss_fn, device, epochs=3, benchmark=False):
+    """training/train.py:138-152: the whole graph every epoch; accuracy on the test mask per epoch."""
+    trainer = Trainer_Flickr(model, optimizer, loss_fn, device)
+    start = time.time()
+    for epoch in range(epochs):
+        loss = trainer.train(data)
+        if not benchmark:
+            print(f"Epoch {epoch + 1:03d} | Loss: {loss:.4f} | Test Acc: {trainer.test(data):.4f}")
+    if benchmark:
+        elapsed = time.time() - start
+        print(f"Training Time: {elapsed:.4f} seconds")
+        print(f"Troughput: {epochs / elapsed:.3f} epoch/sec")
+
+
+def Train_ModelNet(model, data_loader, optimizer, loss_fn, device, epochs=3, benchmark=False):
+    """training/train.py:155-176: (train, test) loaders; no per-epoch report, test loss after a benchmark."""
+    train_loader, test_loader = data_loader
+    _epochs(Trainer_ModelNet(model, optimizer, loss_fn, device), train_loader, None, test_loader, device, epochs,
+            benchmark, "", "Validation Loss")
+
+
+def Train_ModelNet_FB(model, data_loader, optimizer, loss_fn, device, epochs=3, benchmark=False):
+    """training/train.py:178-195: one full batch per split; test loss per epoch."""
+    train_set, test_set = data_loader
+    _epochs(Trainer_ModelNet(model, optimizer, loss_fn, device), train_set, test_set, None, device, epochs,
+            benchmark, "Test Loss", "")

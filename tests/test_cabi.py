@@ -116,7 +116,9 @@ def test_drop_in_package_mirrors_the_reference_imports():
     import importlib
     import sys
     import mpnn_amd
-    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "models" or k.startswith("models.")}
+    import mpnn_amd.datasets
+    import mpnn_amd.train
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split(".")[0] in ("models", "training", "data")}
     sys.path.insert(0, os.path.join(ROOT, "integration"))
     try:
         models = importlib.import_module("models")
@@ -126,8 +128,15 @@ def test_drop_in_package_mirrors_the_reference_imports():
         assert mp.MPNN_QM9 is mpnn_amd.MPNN_QM9 and mp.MPNN_ModelNet is mpnn_amd.MPNN_ModelNet
         layers = importlib.import_module("models.layers")
         assert layers.MPNNLayerSum is mpnn_amd.MPNNLayerSum
+        tr = importlib.import_module("training.train")            # experiments: `import training.train as train`
+        for name in ("Trainer_QM9", "Trainer_Flickr", "Trainer_ModelNet", "Train_QM9", "Train_QM9_FB", "Train_Flickr",
+                     "Train_ModelNet", "Train_ModelNet_FB"):
+            assert getattr(tr, name) is getattr(mpnn_amd.train, name)
+        ds = importlib.import_module("data.dataset")              # experiments: `from data.dataset import ...`
+        for name in ("FlickrDataset", "QM9Dataset", "ModelNetDataset", "S3DISDataset"):
+            assert getattr(ds, name) is getattr(mpnn_amd.datasets, name)
     finally:
         sys.path.remove(os.path.join(ROOT, "integration"))
-        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("models", "training", "data")]:
             del sys.modules[k]
         sys.modules.update(saved)

@@ -88,3 +88,33 @@ def test_s3dis_stand_in_feeds_a_layer():
     layer = MPNNLayerSum(6, 1, 16).cuda()
     out = layer(batch.x, batch.edge_index, batch.edge_attr)
     assert out.shape == (512, 16) and bool(torch.isfinite(out).all())
+
+
+@pytest.mark.gpu
+def test_epoch_loops_with_the_reference_signatures(capsys):
+    """Train_QM9 / _FB, Train_Flickr, Train_ModelNet / _FB (training/train.py:88-195) on the stand-in datasets."""
+    import inspect
+    from mpnn_amd import MPNN, MPNN_ModelNet, MPNN_QM9, train
+    from mpnn_amd.datasets import FlickrDataset, ModelNetDataset, QM9Dataset
+    from mpnn_amd.optim import FlatAdam
+    for name in ("Train_QM9", "Train_QM9_FB", "Train_Flickr", "Train_ModelNet", "Train_ModelNet_FB"):
+        assert list(inspect.signature(getattr(train, name)).parameters)[2:] == ["optimizer", "loss_fn", "device", "epochs", "benchmark"]
+    qm9 = QM9Dataset(num_graphs=120)
+    model = MPNN_QM9(11, 4, 16, 19, num_layers=2, mode="sum").cuda()
+    opt = FlatAdam(model.parameters(), lr=1e-2)
+    train.Train_QM9(model, qm9.get_loader(batch_size=32), opt, F.mse_loss, "cuda", epochs=2)
+    train.Train_QM9_FB(model, qm9.get_full_graphs(), opt, F.mse_loss, "cuda", epochs=2, benchmark=True)
+    out = capsys.readouterr().out
+    assert out.count("| Test Loss: ") == 2 and "Epoch 002 | Loss: " in out
+    assert "Training Time: " in out and "epoch/sec" in out and "Validation Loss: " in out
+    flickr = FlickrDataset(num_nodes=2000, num_edges=12000, num_features=20)
+    fm = MPNN(20, 16, 7, num_layers=2, mode="cat").cuda()
+    train.Train_Flickr(fm, flickr.get_data(), FlatAdam(fm.parameters(), lr=1e-2), F.cross_entropy, "cuda", epochs=2)
+    assert capsys.readouterr().out.count("| Test Acc: ") == 2
+    mn = ModelNetDataset(train_clouds=8, test_clouds=4, points=64, k=6)
+    mm = MPNN_ModelNet(3, 1, 16, 10, num_layers=2, mode="sum").cuda()
+    mo = FlatAdam(mm.parameters(), lr=1e-2)
+    train.Train_ModelNet(mm, mn.get_loaders(batch_size=4), mo, F.cross_entropy, "cuda", epochs=1, benchmark=True)
+    train.Train_ModelNet_FB(mm, mn.get_full_graphs(), mo, F.cross_entropy, "cuda", epochs=2)
+    out = capsys.readouterr().out
+    assert "Validation Loss: " in out and out.count("| Test Loss: ") == 2
