@@ -48,7 +48,9 @@ for c in range(cases):
     worst["pool"] = max(worst["pool"], rel(got, want), rel(xg.grad, xw.grad))
     assert worst["pool"] < 1e-5, f"case {c} pool n={n} H={H} B={B}: {worst['pool']:.2e}"
     # ---- EGNN edge operator
-    n, e, H, Fe = R(1, 500), R(0, 8000), R(1, 32) * 4, R(1, 5)
+    # (at least two nodes: with one node every edge is a self loop, the two halves of the coordinate gradient cancel
+    # exactly in float64 and only to float32 rounding of their thousands of terms on the GPU)
+    n, e, H, Fe = R(2, 500), R(0, 8000), R(1, 32) * 4, R(1, 5)
     skew = R(0, 1)
     dst = ((torch.rand(e, generator=g) ** 6 * n).long().clamp_(max=n - 1) if skew else torch.randint(0, n, (e,), generator=g))
     ei = torch.stack([torch.randint(0, n, (e,), generator=g), dst])
