@@ -151,3 +151,33 @@ def test_default_chunk_rule():
     for e, want in [(0, 64), (899_756, 64), (2 ** 23 - 1, 64), (2 ** 23, 128), (9_000_000, 128), (2 ** 24, 256),
                     (2 ** 26 - 1, 512), (2 ** 26, 1024), (100_000_000, 1024), (2 ** 31 - 1, 1024)]:
         assert default_chunk(e) == want, (e, default_chunk(e), want)
+
+
+def test_rows_in_work_item_order_host_logic():
+    """graph._rows_into_item_order (host-side tensor code, runs on any device) moves whole rows of a sorted view
+    into the order in which the oracle's work_items lists them and keeps every row's edges as they were."""
+    from mpnn_amd.graph import CSR, _rows_into_item_order
+    gen = torch.Generator().manual_seed(4)
+    n, e, chunk = 300, 9000, 16
+    dst = (torch.rand(e, generator=gen) ** 4 * n).long().clamp_(max=n - 1)     # skewed: long rows that get split
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), dst])
+    ref = O.csr_build(ei, n)
+    csr = CSR()
+    csr.num_rows, csr.num_cols, csr.num_edges, csr.order = n, n, e, None
+    csr.rowptr, csr.col, csr.eid = ref["rowptr"].clone(), ref["col"].clone(), ref["eid"].clone()
+    _rows_into_item_order(csr, torch.zeros(4, dtype=torch.int32), chunk)
+    items, split, _ = O.work_items(ref["rowptr"], chunk, 256)
+    rows_in_item_order = list(dict.fromkeys(items[:, 0].tolist()))            # first appearance of every row
+    assert csr.order.tolist() == rows_in_item_order and split.numel() > 0
+    assert csr.rowptr.dtype == torch.int32 and int(csr.rowptr[0]) == 0 and int(csr.rowptr[-1]) == e
+    for j in (0, 1, 7, n // 2, n - 1):
+        row = int(csr.order[j])
+        got = slice(int(csr.rowptr[j]), int(csr.rowptr[j + 1]))
+        want = slice(int(ref["rowptr"][row]), int(ref["rowptr"][row + 1]))
+        assert torch.equal(csr.col[got], ref["col"][want]) and torch.equal(csr.eid[got], ref["eid"][want])
+    assert torch.equal(csr.degree(), ref["rowptr"][1:] - ref["rowptr"][:-1])
+    # work items of the moved view are one ascending run over the edge arrays
+    moved, _, _ = O.work_items(csr.rowptr, chunk, 256)
+    assert torch.equal(moved[1:, 1], moved[:-1, 2]) and int(moved[0, 1]) == 0 and int(moved[-1, 2]) == e
+    with pytest.raises(IndexError):
+        _rows_into_item_order(csr, torch.ones(4, dtype=torch.int32), chunk)
