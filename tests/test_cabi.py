@@ -140,3 +140,13 @@ def test_drop_in_package_mirrors_the_reference_imports():
         for k in [k for k in sys.modules if k.split(".")[0] in ("models", "training", "data")]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_leading_dimension_of_single_row_matrices():
+    """A one-row matrix keeps whatever stride(0) torch left it (1 after transposing a one-column matrix); the GEMM
+    wrappers must pass a leading dimension that the C ABI's `ld >= K` check accepts."""
+    from mpnn_amd.dense import _ld
+    w = torch.zeros(6, 1).t().contiguous()          # [1, 6] with stride (1, 1)
+    assert w.shape == (1, 6) and _ld(w) >= 6
+    assert _ld(torch.zeros(5, 8)) == 8 and _ld(torch.zeros(5, 16)[:, :8]) == 16 and _ld(None) == 0
+    assert _ld(torch.zeros(1, 16)[:, :8]) >= 8
