@@ -71,11 +71,14 @@ class EGNNLayer(torch.nn.Module):
 
     h, pos -> relu(linear_out([h | sum_e m_e])),  pos + sum_e (pos_i - pos_j) * coord_linear(m_e)
     with m_e = relu(xs_i + xt_j + linear_3(edge_attr)) as in models/layers.py:104-110,128 and coord_linear a
-    bias-free Linear(H, 1).  The message sum and the coordinate update share one edge pass.
+    bias-free Linear(H, 1).  The message sum and the coordinate update share one edge pass, which exists for the
+    16-byte vector layout only: ``out_channels`` must be a multiple of 4 (8 for bfloat16 models) and at most 256.
     """
 
     def __init__(self, in_channels, edge_channels, out_channels):
         super().__init__()
+        if out_channels % 4 or not 0 < out_channels <= 256:
+            raise ValueError(f"EGNNLayer needs out_channels to be a multiple of 4 in [4, 256], got {out_channels}")
         self.in_channels, self.edge_channels, self.out_channels = in_channels, edge_channels, out_channels
         self.fused_linear = Linear(in_channels, out_channels * 2, bias=False)
         self.linear_3 = Linear(edge_channels, out_channels, bias=False)

@@ -50,7 +50,7 @@ for c in range(cases):
     # ---- EGNN edge operator
     # (at least two nodes: with one node every edge is a self loop, the two halves of the coordinate gradient cancel
     # exactly in float64 and only to float32 rounding of their thousands of terms on the GPU)
-    n, e, H, Fe = R(2, 500), R(0, 8000), R(1, 32) * 4, R(1, 5)
+    n, e, H, Fe = R(2, 500), R(0, 8000), R(1, 64) * 4, R(1, 5)     # the EGNN pass exists for widths 4, 8, .., 256
     skew = R(0, 1)
     dst = ((torch.rand(e, generator=g) ** 6 * n).long().clamp_(max=n - 1) if skew else torch.randint(0, n, (e,), generator=g))
     ei = torch.stack([torch.randint(0, n, (e,), generator=g), dst])

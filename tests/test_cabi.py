@@ -150,3 +150,10 @@ def test_leading_dimension_of_single_row_matrices():
     assert w.shape == (1, 6) and _ld(w) >= 6
     assert _ld(torch.zeros(5, 8)) == 8 and _ld(torch.zeros(5, 16)[:, :8]) == 16 and _ld(None) == 0
     assert _ld(torch.zeros(1, 16)[:, :8]) >= 8
+
+
+def test_egnn_layer_rejects_widths_without_a_vector_layout():
+    from mpnn_amd import EGNNLayer
+    with pytest.raises(ValueError, match="multiple of 4"):
+        EGNNLayer(8, 2, 38)
+    assert EGNNLayer(8, 2, 40).coord_linear.weight.shape == (1, 40)
