@@ -297,6 +297,38 @@ def test_layer_degenerate_widths(mode, n, e, f, h, fe, dev):
         assert_close(p.grad, w.grad, RTOL32, what="gW")
 
 
+@pytest.mark.parametrize("mode", ["sum", "cat"])
+def test_strided_views_of_the_inputs(mode, dev):
+    """x as a column slice or every second row of a larger array, edge_index as the transposed view of an [E, 2]
+    array, edge_attr as a column slice: same bits as with contiguous inputs."""
+    from mpnn_amd import MPNNLayerCat, MPNNLayerSum
+    gen = torch.Generator().manual_seed(0)
+    n, e, f, h, fe = 500, 4000, 12, 32, 3
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)]).to(dev)
+    x, ea, r = torch.randn(n, f, generator=gen).to(dev), torch.rand(e, fe, generator=gen).to(dev), torch.randn(n, h, generator=gen).to(dev)
+    torch.manual_seed(1)
+    layer = (MPNNLayerSum if mode == "sum" else MPNNLayerCat)(f, fe, h).to(dev)
+
+    def run(x_, ei_, ea_):
+        for p in layer.parameters():
+            p.grad = None
+        out = layer(x_, ei_, ea_)
+        (out * r).sum().backward()
+        return [out.detach()] + [p.grad.clone() for p in layer.parameters()]
+
+    base = run(x, ei, ea)
+    wide = torch.randn(n, f + 5, device=dev)
+    wide[:, 2:2 + f] = x
+    tall = torch.empty(2 * n, f, device=dev)
+    tall[::2] = x
+    ea_wide = torch.zeros(e, fe + 2, device=dev)
+    ea_wide[:, 1:1 + fe] = ea
+    for args in ((wide[:, 2:2 + f], ei, ea), (tall[::2], ei, ea), (x, ei.t().contiguous().t(), ea),
+                 (x, ei, ea_wide[:, 1:1 + fe])):
+        for got, want in zip(run(*args), base):
+            assert torch.equal(got, want)
+
+
 def test_global_mean_pool_golden(dev):
     from mpnn_amd import global_mean_pool
     g = load_golden("pool")
