@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 7
+#define MPNN_ABI_VERSION 8
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -214,6 +214,25 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
                            void* out, int64_t ldo, float* cnt, float* part_out,
                            float* part_cnt, uint32_t* maskbits, int64_t num_nodes, int32_t H,
                            int32_t dtype, mpnn_stream_t stream);
+
+/* mpnn_aggregate_fwd for callers that cannot allocate device memory at all (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc): the partial-sum slabs of split rows (part_out, part_cnt)
+ * live in a device array built into the library instead of being passed in.  No counterpart in the reference.
+ * Every other argument, the arithmetic and the results are those of mpnn_aggregate_fwd (bit for bit).
+ *   - limit: align64(n_parts * H) floats, twice that when cnt != NULL, must fit MPNN_NOALLOC_SCRATCH_BYTES;
+ *     beyond it the call fails with MPNN_E_CAPACITY and touches nothing;
+ *   - the call itself performs no allocation, free or synchronisation; the first call on a device looks the
+ *     array's address up (hipGetSymbolAddress), so make that first call outside a stream capture;
+ *   - each GPU holds one array for the whole process: calls that overlap on one GPU (different streams) race on
+ *     it - order them on one stream or use mpnn_aggregate_fwd with separate slabs.  Contents are not kept
+ *     between calls and nothing needs clearing (every piece writes its slab row before it is read). */
+#define MPNN_NOALLOC_SCRATCH_BYTES (16 << 20)
+int32_t mpnn_aggregate_fwd_noalloc(const void* A, int64_t ldA, const void* B, int64_t ldB,
+                                   const void* ea_sorted, int32_t Fe, const void* We,
+                                   const int32_t* col, const int32_t* items, int64_t n_items,
+                                   const int32_t* split, int64_t n_split, int64_t n_parts,
+                                   void* out, int64_t ldo, float* cnt, uint32_t* maskbits,
+                                   int64_t num_nodes, int32_t H, int32_t dtype, mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Backward of the aggregation with respect to B (the per-source table) and We.

@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -61,6 +61,10 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                      c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
                                      c_int32, c_void_p]),
+    "mpnn_aggregate_fwd_noalloc": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
+                                             c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                             c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                                             c_int32, c_void_p]),
     "mpnn_bwd_scratch_floats": (c_int64, [c_int32, c_int32]),
     "mpnn_mask_words": (c_int32, [c_int32, c_int32]),
     "mpnn_aggregate_bwd_src_masked": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,

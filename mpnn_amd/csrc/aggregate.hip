@@ -684,6 +684,70 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
                             part_out, part_cnt, maskbits, H, g, stream);
 }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------
+// Forward entry point that allocates nothing: the partial-sum slabs of split rows live in a
+// file-scope device array instead of caller-provided scratch.
+// ---------------------------------------------------------------------------------------
+namespace mpnn {
+
+constexpr int64_t kNoAllocFloats = MPNN_NOALLOC_SCRATCH_BYTES / (int64_t)sizeof(float);
+static __device__ __align__(256) float scratch[kNoAllocFloats];
+
+// Every GPU holds its own copy of `scratch` at its own address; the name above is only a host-side handle.
+// The device address is looked up once per device (with that device current) and kept here.
+constexpr int kMaxDevices = 64;
+static float* g_scratch_ptr[kMaxDevices];
+
+static int32_t noalloc_scratch(float** out) {
+  int dev = -1;
+  MPNN_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd_noalloc: device %d out of range", dev);
+  float* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!p) {
+    // two threads racing here both obtain the same address for this device
+    MPNN_HIP_CHECK(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+    if (!p) return fail(MPNN_E_HIP, "mpnn_aggregate_fwd_noalloc: hipGetSymbolAddress returned a null address");
+    __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);
+  }
+  *out = p;
+  return MPNN_OK;
+}
+
+}  // namespace mpnn
+
+extern "C" {
+
+int32_t mpnn_aggregate_fwd_noalloc(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea_sorted,
+                                   int32_t Fe, const void* We, const int32_t* col, const int32_t* items,
+                                   int64_t n_items, const int32_t* split, int64_t n_split, int64_t n_parts, void* out,
+                                   int64_t ldo, float* cnt, uint32_t* maskbits, int64_t num_nodes, int32_t H,
+                                   int32_t dtype, mpnn_stream_t stream) {
+  if (H < 1 || n_parts < 0) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd_noalloc: H=%d n_parts=%lld", H, (long long)n_parts);
+  float* part_out = nullptr;
+  float* part_cnt = nullptr;
+  if (n_parts > 0) {
+    // slab layout inside the array: [n_parts][H] partial sums, then (training) [n_parts][H] partial counts,
+    // each slab starting on a 256-byte boundary
+    const int64_t slab = align_up(n_parts * (int64_t)H, 64);
+    const int64_t need = slab * (cnt ? 2 : 1);
+    if (need > kNoAllocFloats)
+      return fail(MPNN_E_CAPACITY,
+                  "mpnn_aggregate_fwd_noalloc: %lld split pieces of %d columns need %lld bytes of scratch, the built-in "
+                  "array holds %lld; use mpnn_aggregate_fwd with caller-provided slabs",
+                  (long long)n_parts, H, (long long)(need * 4), (long long)MPNN_NOALLOC_SCRATCH_BYTES);
+    float* base = nullptr;
+    const int32_t rc = noalloc_scratch(&base);
+    if (rc != MPNN_OK) return rc;
+    // Nothing has to start at zero: every piece writes its whole slab row before k_reduce_split reads it.
+    part_out = base;
+    part_cnt = cnt ? base + slab : nullptr;
+  }
+  return mpnn_aggregate_fwd(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, n_parts, out, ldo,
+                            cnt, part_out, part_cnt, maskbits, num_nodes, H, dtype, stream);
+}
+
 int32_t mpnn_mask_words(int32_t H, int32_t dtype) {
   if (H < 1 || (dtype != MPNN_F32 && dtype != MPNN_BF16)) return 0;
   const Geometry g = geometry(H, dtype, true);
