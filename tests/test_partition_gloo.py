@@ -67,6 +67,7 @@ def _init(rank, world, port, out_dir):
     """File rendezvous in the test's own directory: no fixed port that another process could take between the
     moment it was found free and the moment rank 0 binds it.  (MASTER_* stay set for code that reads them.)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # the container's hostname need not resolve
     dist.init_process_group("gloo", init_method=f"file://{os.path.join(out_dir, 'rendezvous')}", rank=rank,
                             world_size=world)
 
