@@ -7,7 +7,13 @@ A step is one full forward + backward of one MPNN layer (node GEMMs, fused gathe
 aggregate pass, update GEMM, and every gradient: x, all weights) on a synthetic graph whose
 tensors are already in HBM.  With N > 1 the graph is partitioned by destination range and the
 step includes the halo all-gather, the reduce-scatter of the halo gradient and the weight
-gradient all-reduce (one process per GPU, launched by torch.distributed.run).
+gradient all-reduce (one process per GPU).  Started without a launcher (`python bench.py --gpus N`, no
+WORLD_SIZE in the environment) the script starts N ranks itself through torch.distributed.run, as a child
+process and before anything touches the GPU.
+
+After the timed region the single-GPU run checks itself: one more forward + backward with an upstream
+gradient that is zero outside a sample of target rows is compared, output rows and every gradient, with the
+CPU oracle evaluated on the edges that touch the sample (`verified`); a mismatch makes the run fail.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant HIP kernel (timed with events on
 the stream it runs on, inside the timed region); `cpu_baseline` is the CPU oracle timed on the
@@ -98,50 +104,166 @@ def pmc_traffic(workload, dtype, kernel):
             continue
         for v in rec.get("kernels", {}).get(workload, {}).values():
             if v.get("bench_kernel") == kernel:
-                return v["hbm_bytes_per_launch"]
-    return None
+                return v["hbm_bytes_per_launch"], (f"{os.path.relpath(path, ROOT)}: separate rocprofv3 --pmc passes of "
+                                                   "this command in the builder's session, not counters of this run")
+    return None, None
 
 
-def cpu_baseline(name, mode, target_seconds=20.0):
+# Sample of the workload the CPU oracle is timed on: (scale of the generator, timed runs after one warm-up).
+# The cat form materialises [E, 2F+Fe] rows and their gradient, six times the sum form's work per edge, so its
+# sample of the power-law graph is smaller.
+CPU_SAMPLE = {
+    ("powerlaw", "sum"): (0.1, 1), ("powerlaw", "cat"): (0.02, 1),
+    ("flickr", "sum"): (1.0, 5), ("flickr", "cat"): (1.0, 2),
+    ("modelnet", "sum"): (1.0, 5), ("modelnet", "cat"): (1.0, 5),
+    ("qm9", "sum"): (1.0, 5), ("qm9", "cat"): (1.0, 5),
+}
+
+
+def cpu_baseline(name, mode, layer="mpnn"):
     """CPU oracle (plain torch ops, the arithmetic the reference runs through PyG) on a bounded sample."""
     from oracle import reference_oracle as O
     cfg = WORKLOADS[name]
-    scale = {"powerlaw": 0.02, "flickr": 1.0, "modelnet": 1.0, "qm9": 1.0}[name]
+    scale, runs = CPU_SAMPLE[(name, mode)]
     d = make_data(name, "cpu", scale=scale, seed=0)
     x, ei, ea = d["x"].float(), d["edge_index"], d["edge_attr"].float()
     F_in, H, Fe = x.size(1), cfg["H"], ea.size(1)
     gen = torch.Generator().manual_seed(1)
     w_out = (torch.rand(H, H + F_in, generator=gen) - 0.5).requires_grad_(True)
-    if mode == "cat":
-        ws = [(torch.rand(H, 2 * F_in + Fe, generator=gen) - 0.5).requires_grad_(True), w_out]
-        fn = lambda xx: O.layer_cat(xx, ei, ea, ws[0], ws[1])
-    else:
-        ws = [(torch.rand(2 * H, F_in, generator=gen) - 0.5).requires_grad_(True),
-              (torch.rand(H, Fe, generator=gen) - 0.5).requires_grad_(True), w_out]
-        fn = lambda xx: O.layer_sum(xx, ei, ea, ws[0], ws[1], ws[2])
     x = x.requires_grad_(True)
     r = torch.randn(x.size(0), H, generator=gen)
+    if layer == "egnn":
+        pos = (d["pos"].float() if "pos" in d else torch.randn(x.size(0), 3, generator=gen)).requires_grad_(True)
+        rp = torch.randn(x.size(0), 3, generator=gen)
+        ws = [(torch.rand(2 * H, F_in, generator=gen) - 0.5).requires_grad_(True),
+              (torch.rand(H, Fe, generator=gen) - 0.5).requires_grad_(True), w_out,
+              ((torch.rand(H, generator=gen) - 0.5) / H).requires_grad_(True)]
 
-    def step():
-        out = fn(x)
-        torch.autograd.grad((out * r).sum(), [x] + ws)
+        def step():
+            ab = torch.nn.functional.linear(x, ws[0])
+            aggr, pos_out = O.egnn_layer(ab[:, :H], ab[:, H:], ea, ws[1], pos, ws[3], ei)
+            out = O.update(x, aggr, ws[2])
+            torch.autograd.grad((out * r).sum() + (pos_out * rp).sum(), [x, pos] + ws)
+        what = "EGNN layer (sum-form message + coordinate update)"
+    else:
+        if mode == "cat":
+            ws = [(torch.rand(H, 2 * F_in + Fe, generator=gen) - 0.5).requires_grad_(True), w_out]
+            fn = lambda xx: O.layer_cat(xx, ei, ea, ws[0], ws[1])
+        else:
+            ws = [(torch.rand(2 * H, F_in, generator=gen) - 0.5).requires_grad_(True),
+                  (torch.rand(H, Fe, generator=gen) - 0.5).requires_grad_(True), w_out]
+            fn = lambda xx: O.layer_sum(xx, ei, ea, ws[0], ws[1], ws[2])
+
+        def step():
+            out = fn(x)
+            torch.autograd.grad((out * r).sum(), [x] + ws)
+        what = f"MPNNLayer{mode.capitalize()}"
 
     step()  # warm-up
-    t0 = time.perf_counter()
-    step()
-    one = time.perf_counter() - t0
-    reps = max(1, min(10, int(target_seconds / max(one, 1e-3)) - 1))
-    times = [one]
-    for _ in range(reps):
+    times = []
+    for _ in range(runs):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
     med = sorted(times)[len(times) // 2]
     return {
         "value": ei.size(1) / med, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{name} generator at scale {scale} (N={x.size(0)}, E={ei.size(1)}), MPNNLayer{mode.capitalize()} "
-                  f"fwd+bwd with plain torch CPU ops, median of {len(times)} runs after 1 warm-up",
+        "sample": f"{name} generator at scale {scale} (N={x.size(0)}, E={ei.size(1)}), {what} "
+                  f"fwd+bwd with plain torch CPU ops, median of {len(times)} run(s) after 1 warm-up",
     }
+
+
+def verify_layer(layer, mode, x, ei, ea, n_total):
+    """One more forward + backward of `layer`, checked against the CPU oracle on a sample of rows.
+
+    The upstream gradient is zero outside the sampled target rows (the largest hub, four more rows of the top 64 and
+    2,000 random rows), so every gradient - input rows and all weights - depends only on the edges into the
+    sample, which the oracle evaluates in float64 (oracle/sampled.py); the kernels still walk every edge."""
+    from oracle import reference_oracle as O
+    from oracle import sampled as S
+    dev = x.device
+    H = layer.out_channels
+    rows = S.sample_rows(ei, n_total, 1, 2000, hubs=1, seed=7)
+    gen = torch.Generator(device=dev).manual_seed(8)
+    gy_rows = torch.randn(rows.numel(), H, generator=gen, device=dev)
+    gy = torch.zeros(n_total, H, device=dev)
+    gy[rows] = gy_rows
+    params = list(layer.parameters())
+    for p in params:
+        p.grad = None
+    xg = x.detach().float().requires_grad_(True)
+    y = layer(xg, ei, ea.float())
+    y.backward(gy)
+    fn = O.layer_sum if mode == "sum" else O.layer_cat
+    want = S.layer_sparse_upstream(fn, xg, ei, ea, [p.detach() for p in params], rows, gy_rows)
+    nodes = want["nodes"]
+    pairs = [("y[rows]", y.detach()[rows], want["y_rows"]), ("grad x[nodes]", xg.grad[nodes], want["gx"])]
+    pairs += [(f"grad {k}", p.grad, w) for (k, _), p, w in zip(layer.named_parameters(), params, want["gw"])]
+    rep = S.error_report(pairs, 1e-5)
+    untouched = torch.ones(n_total, dtype=torch.bool, device=dev)
+    untouched[nodes] = False
+    stray = float(xg.grad[untouched].abs().max()) if bool(untouched.any()) else 0.0
+    if stray != 0.0:
+        rep["ok"], rep["worst"] = False, f"input-gradient rows no sampled edge reaches are not zero (max {stray})"
+    for p in params:
+        p.grad = None
+    return {"ok": rep["ok"], "rows": int(rows.numel()), "input_rows": int(nodes.numel()),
+            "edges": want["num_edges"], "entries": rep["entries"], "max_rel_err": rep["max_rel_err"],
+            "outside_tolerance": rep["outside"], "tolerance": "|got-want| <= 1e-5*max|want| + 1e-5*|want| against "
+            "the float64 CPU oracle; at most 1e-5 of a tensor's entries outside (relu kinks)",
+            "what": "y rows, grad x, grad of every weight; sparse upstream gradient on the sampled target rows",
+            "worst": rep["worst"]}
+
+
+def model_step_time(mode, d, hidden, dev, steps=5, warmup=2):
+    """Whole training step of the reference's loop (training/train.py:43-49) on the workload's graph: 2 layers + head
+    (models/mpnn.py:86-101), cross-entropy over the masked rows, backward, Adam.  Returns seconds per step."""
+    from mpnn_amd import MPNN
+    from mpnn_amd.loss import masked_cross_entropy
+    from mpnn_amd.optim import FlatAdam
+    x, ei, ea, n = d["x"].detach().float(), d["edge_index"], d["edge_attr"].float(), d["num_nodes"]
+    classes = 7
+    gen = torch.Generator(device=dev).manual_seed(5)
+    y = d.get("y")
+    if y is None or y.dim() != 1 or y.numel() != n or y.dtype != torch.int64:
+        y = torch.randint(0, classes, (n,), generator=gen, device=dev)
+    mask = d.get("train_mask")
+    if mask is None:
+        mask = torch.rand(n, generator=gen, device=dev) < 0.5
+    torch.manual_seed(0)
+    model = MPNN(x.size(1), hidden, classes, num_layers=2, mode=mode).to(dev)
+    opt = FlatAdam(model.parameters(), lr=0.01)
+
+    def step():
+        opt.zero_grad()
+        loss = masked_cross_entropy(model(x, ei, ea), y, mask)
+        loss.backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process
+    (nothing in this process has touched the GPU yet, and it never will) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    note(f"no launcher in the environment: starting {args.gpus} ranks with torch.distributed.run on port {port}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def note(msg):
@@ -162,6 +284,8 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debugging only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the sampled check against the CPU oracle")
+    ap.add_argument("--no-model-step", action="store_true", help="skip the whole-model training step timing")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture one step (forward+backward) into a HIP graph and time replays (single GPU)")
     ap.add_argument("--first-layer", action="store_true",
@@ -174,12 +298,13 @@ def main():
     if os.environ.get("BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
-                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus differ")
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -248,6 +373,7 @@ def main():
         ea = pg.local_edges(d["edge_attr"]).to(dtype).clone()
         n_rows_fwd, n_rows_bwd, e_local = pg.n_local, world * pg.n_pad, pg.edge_ids.numel()
         forward = lambda: partitioned_layer(layer, x, pg, ea)
+    keep = d if world == 1 else None      # the single-GPU run checks itself and times a model step afterwards
     del d
     torch.cuda.empty_cache()
     note("graph structures built; warming up")
@@ -295,11 +421,17 @@ def main():
         fence()
     note("timing")
     ops.EVENT_SINK = [] if run_step is step else None
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    cur = torch.cuda.current_stream(dev)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record(cur)
+    for i in range(args.steps):
         run_step()
+        marks[i + 1].record(cur)
     fence()
     elapsed = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if step_ms else None
     events, ops.EVENT_SINK = ops.EVENT_SINK or [], None
     if run_step is not step:
         # graph replays carry no events: time the kernels over a few eager steps after the timed region
@@ -335,6 +467,9 @@ def main():
             b = kernel_bytes(k, rows[k], e_local, H, Fe, s, mask_words)
             per_kernel[k] = {"avg_ms": tk * 1e3, "algorithmic_bytes": b, "GBps": b / tk / 1e9}
         dom = max(kavg, key=kavg.get)
+        traffic = traffic_src = None
+        if world == 1 and args.scale == 1.0 and args.mode == "sum":
+            traffic, traffic_src = pmc_traffic(args.workload, args.dtype, dom)
         mp_time = sum(kavg.values())
         model_bytes = layer_bytes_model(n_rows_fwd, e_local, H, Fe, s)
         result = {
@@ -342,6 +477,7 @@ def main():
             "value": e_job / (elapsed / args.steps),
             "unit": "edges/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "ms_per_step_median_events": median_ms,
             "higher_is_better": True,
             "scaling": "weak" if data_parallel else "strong",
             "vs_baseline": None,
@@ -352,14 +488,13 @@ def main():
                        "num_nodes": n_total, "num_edges": e_total,
                        "in_features": F_in, "hidden": H, "edge_features": Fe,
                        "parallelism": "single GPU" if world == 1 else (
-                           f"data parallel x{world}: one batch per rank + gradient all-reduce" if data_parallel
-                           else f"dst-range partition x{world} + halo all-gather"),
+                           (f"data parallel x{world}: one batch per rank + gradient all-reduce" if data_parallel
+                            else f"dst-range partition x{world} + halo all-gather")
+                           + f" ({dist.get_backend()} reports {dist.get_world_size()} ranks)"),
                        "launch": "HIP graph replay" if run_step is not step else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args.workload, args.dtype, dom) if (world == 1 and args.scale == 1.0
-                                                                                     and args.mode == "sum"
-                                                                                     and args.layer == "mpnn") else None},
+                         "traffic": traffic, "traffic_source": traffic_src},
             "kernels": per_kernel,
             "message_passing_only": {
                 "ms": mp_time * 1e3, "edges_per_sec": e_local / mp_time,
@@ -372,9 +507,39 @@ def main():
                 "note": "dst-sorted CSR + src-sorted transpose + work items from edge_index; paid once for a static "
                         "graph, once per mini-batch for batched workloads",
                 "edges_per_sec_if_rebuilt_every_step": e_total / (elapsed / args.steps + graph_build_ms * 1e-3)}
-        if world == 1 and not args.no_cpu_baseline and args.layer == "mpnn":
-            result["cpu_baseline"] = cpu_baseline(args.workload, args.mode)
+        failed = None
+        if world == 1 and keep is not None and args.layer == "mpnn" and not args.no_verify:
+            note("checking a sample of rows against the CPU oracle")
+            if args.dtype == "f32":
+                result["verified"] = verify_layer(layer, args.mode, keep["x"], keep["edge_index"], keep["edge_attr"],
+                                                  n_total)
+                if not result["verified"]["ok"]:
+                    failed = f"verification against the CPU oracle failed: {result['verified']['worst']}"
+            else:
+                # bfloat16 storage moves ~0.3 % of the relu decisions against a float64 evaluation, so single
+                # gradient entries differ by whole terms: the elementwise sampled check is a float32 check
+                # (tests/test_gpu_parity.py holds the bfloat16 layer tests)
+                result["verified"] = None
+        if world == 1 and keep is not None and args.layer == "mpnn" and args.dtype == "f32" and not args.no_model_step:
+            note("timing the whole-model training step")
+            del x, r
+            layer = None
+            torch.cuda.empty_cache()
+            t_model = model_step_time(args.mode, keep, H, dev)
+            result["model_step"] = {
+                "ms": t_model * 1e3, "edges_per_sec": 2 * e_total / t_model,
+                "what": "MPNN(2 layers, hidden %d) + head + masked cross-entropy + backward + Adam on the same graph "
+                        "(training/train.py:43-49); edges_per_sec counts both layers" % H}
+        keep = None
+        if world == 1 and not args.no_cpu_baseline:
+            note("timing the CPU oracle")
+            result["cpu_baseline"] = cpu_baseline(args.workload, args.mode, args.layer)
+            if args.layer == "mpnn":
+                other = "cat" if args.mode == "sum" else "sum"
+                result["cpu_baseline_other_form"] = cpu_baseline(args.workload, other)
         print(json.dumps(result), flush=True)
+        if failed:
+            raise SystemExit(failed)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

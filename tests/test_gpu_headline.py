@@ -1,0 +1,110 @@
+"""The benchmark's headline configuration checked at its own size against the CPU oracle.
+
+S3DIS-scale power-law graph, hidden 128, MPNNLayerSum (reference models/layers.py:104-110,128,140), through the
+default graph_for() path: from 2^22 edges on that is the work-item row order with split pieces of
+default_chunk(E) edges - 256 at 25 M edges, 1024 at 100 M.  The CPU oracle cannot evaluate 10^8 edges, so it is
+evaluated (in float64) on the edges that touch a sample of >= 2,000 target rows and >= 2,000 source rows, hubs
+included (oracle/sampled.py says why that is exact).  Bar: 1e-5 relative with the usual floor, plus bitwise
+determinism of a second run.
+"""
+import pytest
+import torch
+
+from mpnn_amd.graph import default_chunk, graph_for
+from oracle import sampled as S
+
+pytestmark = pytest.mark.gpu
+RTOL32 = 1e-5
+SIZES = [pytest.param(1_000_000, 25_000_000, 256, id="1M-25M"),
+         pytest.param(4_000_000, 100_000_000, 1024, id="4M-100M-full")]
+
+
+def _check(pairs):
+    rep = S.error_report(pairs, RTOL32)
+    assert rep["ok"], rep
+    return rep
+
+
+@pytest.mark.parametrize("n,e,chunk", SIZES)
+def test_layer_sum_at_benchmark_size_against_cpu_oracle_on_sampled_rows(n, e, chunk):
+    from mpnn_amd import MPNNLayerSum, synth
+    dev = torch.device("cuda:0")
+    H = 128
+    d = synth.powerlaw(dev, 0, n, e, H, 4)
+    x, ei, ea = d["x"], d["edge_index"], d["edge_attr"]
+    assert default_chunk(e) == chunk
+    graph = graph_for(ei, n)
+    assert graph.by_dst.order is not None and graph.by_src.order is not None    # rows in work-item order
+    assert graph.by_dst.n_split > 0                                            # hubs are cut into pieces
+    torch.manual_seed(0)
+    layer = MPNNLayerSum(H, 4, H).to(dev)
+
+    rows = S.sample_rows(ei, n, 1, 2000, hubs=2, seed=1)
+    assert rows.numel() >= 2000
+    gen = torch.Generator(device=dev).manual_seed(2)
+    gy_rows = torch.randn(rows.numel(), H, generator=gen, device=dev)
+    gy = torch.zeros(n, H, device=dev)
+    gy[rows] = gy_rows            # zero outside the sample: every gradient then depends on the in-edges of `rows` only
+
+    def run():
+        for p in layer.parameters():
+            p.grad = None
+        xg = x.detach().requires_grad_(True)
+        y = layer(xg, ei, ea)
+        y.backward(gy)
+        return [y.detach(), xg.grad] + [p.grad.clone() for p in layer.parameters()]
+
+    got = run()
+    want = S.layer_sum_sparse_upstream(x, ei, ea, layer.fused_linear.weight, layer.linear_3.weight,
+                                       layer.linear_out.weight, rows, gy_rows)
+    nodes = want["nodes"]
+    assert nodes.numel() - rows.numel() >= 2000          # source rows reached through the sampled targets' edges
+    rep = _check([("y[rows]", got[0][rows], want["y_rows"]), ("grad x[nodes]", got[1][nodes], want["gx"]),
+                  ("grad fused_linear", got[2], want["gw_fused"]), ("grad linear_3", got[3], want["gw_edge"]),
+                  ("grad linear_out", got[4], want["gw_out"])])
+    # no gradient can reach any other input row: those rows are exactly zero
+    touched = torch.zeros(n, dtype=torch.bool, device=dev)
+    touched[nodes] = True
+    assert float(got[1][~touched].abs().max()) == 0.0
+    print(f"\nchecked {want['num_edges']} edges, {rows.numel()} target rows, {nodes.numel()} input rows: {rep}")
+
+    again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,e,chunk", SIZES)
+def test_edge_operator_at_benchmark_size_with_dense_upstream_gradient(n, e, chunk):
+    """The two edge passes alone (mpnn_aggregate_fwd, mpnn_aggregate_bwd_src_masked) with the dense upstream
+    gradient the benchmark feeds: sampled target rows of the output and of d/dA, sampled source rows of d/dB."""
+    from mpnn_amd import synth
+    from mpnn_amd.ops import aggregate_fused
+    dev = torch.device("cuda:0")
+    H = 128
+    d = synth.powerlaw(dev, 1, n, e, 8, 4)
+    ei, ea = d["edge_index"], d["edge_attr"]
+    graph = graph_for(ei, n)
+    assert graph.by_dst.order is not None
+    gen = torch.Generator(device=dev).manual_seed(3)
+    ab = torch.randn(n, 2 * H, generator=gen, device=dev)
+    we = torch.randn(H, 4, generator=gen, device=dev) * 0.5
+    g = torch.randn(n, H, generator=gen, device=dev)
+    dst_rows = S.sample_rows(ei, n, 1, 2000, hubs=2, seed=4)
+    src_rows = S.sample_rows(ei, n, 0, 2000, hubs=8, seed=5)
+    assert dst_rows.numel() >= 2000 and src_rows.numel() >= 2000
+
+    def run():
+        ab_, we_ = ab.detach().requires_grad_(True), we.detach().requires_grad_(True)
+        out = aggregate_fused(ab_, ea, we_, graph)
+        out.backward(g)
+        return out.detach(), ab_.grad, we_.grad
+
+    got = run()
+    want = S.aggregate_rows(ab[:, :H], ab[:, H:], ea, we, ei, g, dst_rows, src_rows)
+    rep = _check([("out[dst rows]", got[0][dst_rows], want["out_rows"]),
+                  ("grad A[dst rows]", got[1][dst_rows, :H], want["ga_rows"]),
+                  ("grad B[src rows]", got[1][src_rows, H:], want["gb_rows"])])
+    print(f"\nchecked {want['num_edges']} edges: {rep}")
+    again = run()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)
