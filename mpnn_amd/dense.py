@@ -4,13 +4,12 @@
 ``update``   : relu(x @ W_out[:, :F]^T + aggr @ W_out[:, F:]^T)  (models/layers.py:69,140, no cat)
 
 Both carry their own backward (input gradients through the same NT kernel with a transposed weight, weight
-gradients through the TN kernel, the relu mask fused into the operand loads).  float32 on the GPU only;
-bfloat16 models keep the library GEMMs of torch for these plain Linear calls.
+gradients through the TN kernel).  float32, or bfloat16 with widths that are multiples of 8, on the GPU only:
+anything else raises - there is no fallback to torch's library GEMMs.
 """
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
@@ -152,18 +151,24 @@ def gemm_tn(g, x, mask=None, out=None, g_out=None, x2=None) -> torch.Tensor:
     return out
 
 
+def _kit(dtype):
+    """(NT product, TN product) of the library for a storage dtype."""
+    return (gemm_nt_bf16, gemm_tn_bf16) if dtype == torch.bfloat16 else (gemm_nt, gemm_tn)
+
+
 class _Project(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return gemm_nt(x, w)
+        return _kit(x.dtype)[0](x, w)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
+        nt, tn = _kit(x.dtype)
         g = _rows(g)
-        gx = gemm_nt(g, w.t().contiguous()) if ctx.needs_input_grad[0] else None
-        gw = gemm_tn(g, x) if ctx.needs_input_grad[1] else None
+        gx = nt(g, w.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gw = tn(g, x) if ctx.needs_input_grad[1] else None
         return gx, gw
 
 
@@ -171,42 +176,60 @@ class _Update(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, aggr, w_out):
         f = x.size(1)
-        y = gemm_nt(x, w_out[:, :f], aggr, w_out[:, f:], relu=True)
+        wx, wa = w_out[:, :f], w_out[:, f:]
+        if x.dtype == torch.bfloat16:
+            wx, wa = wx.contiguous(), wa.contiguous()
+        y = _kit(x.dtype)[0](x, wx, aggr, wa, relu=True)
         ctx.save_for_backward(x, aggr, w_out, y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, aggr, w_out, y = ctx.saved_tensors
+        nt, tn = _kit(x.dtype)
         f = x.size(1)
-        gy = _rows(gy)
+        gz = torch.ops.aten.threshold_backward(_rows(gy), y, 0)    # gy * [y > 0], elementwise
         gx = ga = gw = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wt = w_out.t().contiguous()          # [F+H, H]: rows of W^T are the outputs of the input-gradient GEMMs
             if ctx.needs_input_grad[0]:
-                gx = gemm_nt(gy, wt[:f], mask1=y)
+                gx = nt(gz, wt[:f])
             if ctx.needs_input_grad[1]:
-                ga = gemm_nt(gy, wt[f:], mask1=y)
+                ga = nt(gz, wt[f:])
         if ctx.needs_input_grad[2]:
             gw = torch.empty_like(w_out)
-            gemm_tn(gy, x, mask=y, out=gw, x2=aggr)
+            tn(gz, x, out=gw, x2=aggr)
         return gx, ga, gw
 
 
-def _use_mfma(*ts) -> bool:
-    return all(t.is_cuda and t.dtype == torch.float32 for t in ts)
+def _require(name, *ts) -> None:
+    """The dense operators exist on the GPU only: float32, or bfloat16 with 16-byte rows.  Nothing falls back to
+    torch's library GEMMs."""
+    for t in ts:
+        if not t.is_cuda:
+            raise _lib.MpnnError(f"dense.{name}: operand on {t.device}; the MFMA kernels run on an AMD GPU only")
+    if all(t.dtype == torch.float32 for t in ts):
+        return
+    if all(t.dtype == torch.bfloat16 for t in ts):
+        x = ts[0]
+        if x.size(1) % 8 or any(t.size(0) % 8 for t in ts[-1:]):
+            raise ValueError(f"dense.{name}: bfloat16 operands need widths that are multiples of 8 "
+                             f"(got {[tuple(t.shape) for t in ts]}); pad the feature columns with zeros")
+        return
+    raise TypeError(f"dense.{name}: operands must share float32 or bfloat16, got {[t.dtype for t in ts]}")
 
 
 @torch.compiler.disable
 def project(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    if _use_mfma(x, w):
-        return _Project.apply(x, w)
-    return F.linear(x, w)
+    _require("project", x, w)
+    if x.dtype == torch.bfloat16:
+        x, w = x.contiguous(), w.contiguous()
+    return _Project.apply(x, w)
 
 
 @torch.compiler.disable
 def update(x: torch.Tensor, aggr: torch.Tensor, w_out: torch.Tensor) -> torch.Tensor:
-    if _use_mfma(x, aggr, w_out):
-        return _Update.apply(x, aggr, w_out)
-    f = x.size(1)
-    return F.relu(torch.addmm(F.linear(x, w_out[:, :f]), aggr, w_out[:, f:].t()))
+    _require("update", x, aggr, w_out)
+    if x.dtype == torch.bfloat16:
+        x, aggr = x.contiguous(), aggr.contiguous()
+    return _Update.apply(x, aggr, w_out)

@@ -111,16 +111,16 @@ class _LayerFnBf16(torch.autograd.Function):
         f = x.size(1)
         h = wt.size(1)
         gy = gy if gy.is_contiguous() else gy.contiguous()
+        if gy.data_ptr() % 16:
+            gy = gy.clone()                           # a view into a larger buffer: fresh allocations are aligned
         g_ab = torch.empty_like(ab)
         g_wout = torch.empty((h, f + h), dtype=gy.dtype, device=gy.device) if ctx.needs_input_grad[4] else None
         # gz = gy * [y > 0] is a by-product of the first weight-gradient product (whole 256-byte rows)
-        if g_wout is not None and gy.data_ptr() % 16 == 0:
+        if g_wout is not None:
             gz = torch.empty_like(gy)
             gemm_tn_bf16(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)   # both halves of gW_out in one pass over gy
         else:
             gz = torch.ops.aten.threshold_backward(gy, y, 0)
-            if g_wout is not None:
-                torch.mm(gz.t(), torch.cat([x, aggr], 1), out=g_wout)
         ga = gemm_nt_bf16(gz, wt[f:], emul=cnt, out2=g_ab[:, :h])
         g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
         gx = None
@@ -130,23 +130,119 @@ class _LayerFnBf16(torch.autograd.Function):
         return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
 
 
+class _EgnnLayerFn(torch.autograd.Function):
+    """EGNN layer (message pass + coordinate update in one edge pass, then the update) as one node, float32 or
+    bfloat16 storage, every product on the library's MFMA kernels:
+
+      forward    AB = x Wn^T ; (aggr, pos') = EGNN edge pass(AB, e, We, pos, w_pos) ; y = relu(x Wx^T + aggr Wa^T)
+      backward   gz = gy*[y>0], gW_out = gz^T [x | aggr]            TN GEMM (gz as its by-product when rows are aligned)
+                 ga = gz Wa                                         NT GEMM
+                 gAB, gWe, g_pos, g_wpos = EGNN backward passes     destination view, then source view
+                 gx = gz Wx + gAB Wn ; gWn = gAB^T x                NT GEMM (2 segments), TN GEMM
+    """
+
+    @staticmethod
+    def forward(ctx, x, pos, edge_attr, w_nodes, w_edge, w_out, w_pos, graph: MPGraph):
+        bf = x.dtype == torch.bfloat16
+        nt = gemm_nt_bf16 if bf else gemm_nt
+        x = x if x.is_contiguous() else x.contiguous()
+        f, h = x.size(1), w_out.size(0)
+        ab = nt(x, w_nodes.contiguous())
+        a, b = ab[:, :h], ab[:, h:]
+        pos_c, wp, we = pos.contiguous(), w_pos.contiguous(), w_edge.contiguous()
+        ea_s, ea_t = ops._prepare_egnn(a, b, edge_attr, we, pos_c, wp, graph)
+        aggr, pos_out = ops._run_egnn_forward(a, b, ea_s, we, pos_c, wp, graph)
+        wx, wa = w_out[:, :f], w_out[:, f:]
+        if bf:
+            wx, wa = wx.contiguous(), wa.contiguous()
+        y = nt(x, wx, aggr, wa, relu=True)
+        ctx.save_for_backward(x, ab, aggr, y, pos_c, ea_s, ea_t, w_nodes, we, w_out, wp)
+        ctx.graph = graph
+        return y, pos_out
+
+    @staticmethod
+    def backward(ctx, gy, gp):
+        x, ab, aggr, y, pos, ea_s, ea_t, w_nodes, we, w_out, wp = ctx.saved_tensors
+        bf = x.dtype == torch.bfloat16
+        nt, tn = (gemm_nt_bf16, gemm_tn_bf16) if bf else (gemm_nt, gemm_tn)
+        f, h = x.size(1), w_out.size(0)
+        gy = gy if gy.is_contiguous() else gy.contiguous()
+        if gy.data_ptr() % 16:
+            gy = gy.clone()
+        gp = gp.contiguous().float()
+        wt_out = w_out.t().contiguous()               # [F+H, H]
+        g_ab = torch.empty_like(ab)
+        need_wout = ctx.needs_input_grad[5]
+        rows_aligned = bf or (f % 4 == 0 and h % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (y, x, aggr)))
+        g_wout = None
+        if need_wout and rows_aligned:
+            gz = torch.empty_like(gy)
+            g_wout = torch.empty((h, f + h), dtype=gy.dtype, device=gy.device)
+            tn(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)
+        else:
+            gz = torch.ops.aten.threshold_backward(gy, y, 0)      # gy * [y > 0], elementwise
+            if need_wout:
+                g_wout = tn(gz, x, x2=aggr)
+        ga = nt(gz, wt_out[f:])
+        g_we, g_pos, g_wp = ops._run_egnn_backward(ab[:, :h], ab[:, h:], ga, gp, ea_s, ea_t, we, wp, pos, ctx.graph,
+                                                   g_ab[:, :h], g_ab[:, h:])
+        gx = nt(gz, wt_out[:f], g_ab, w_nodes.t().contiguous()) if ctx.needs_input_grad[0] else None
+        g_wn = tn(g_ab, x) if ctx.needs_input_grad[3] else None
+        return (gx, g_pos if ctx.needs_input_grad[1] else None, None, g_wn,
+                g_we if ctx.needs_input_grad[4] else None, g_wout, g_wp if ctx.needs_input_grad[6] else None, None)
+
+
 def supported(x, edge_attr, *weights) -> bool:
+    """float32 on the GPU, or bfloat16 with a hidden width that is a multiple of 8 (16-byte rows; the input width
+    may be anything - layer_forward pads it with zero columns)."""
     if not x.is_cuda:
         return False
     ts = (x, edge_attr) + weights
     if all(t.dtype == torch.float32 for t in ts):
         return True
-    # bfloat16: every width a multiple of 8 (16-byte rows); weights are checked by their shapes
     if all(t.dtype == torch.bfloat16 for t in ts):
-        h = weights[-1].size(0)
-        return x.dim() == 2 and x.size(1) % 8 == 0 and h % 8 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0
+        return x.dim() == 2 and weights[-1].size(0) % 8 == 0
     return False
+
+
+def _pad_features(x, w_nodes, w_out):
+    """bfloat16 rows must be 16 bytes wide: an input width that is not a multiple of 8 (QM9: 11 atom features,
+    point clouds: 3 coordinates) is padded with zero columns, in x and in the weight columns that meet it.  The
+    pads are differentiable copies, so the gradients come back in the unpadded shapes."""
+    f = x.size(1)
+    pad = -f % 8
+    if pad == 0 and x.data_ptr() % 16 == 0 and x.is_contiguous():
+        return x, w_nodes, w_out
+    pad_cols = torch.nn.functional.pad
+    x = pad_cols(x, (0, pad)) if pad else x.clone(memory_format=torch.contiguous_format)
+    if pad:
+        w_nodes = pad_cols(w_nodes, (0, pad))
+        w_out = torch.cat([pad_cols(w_out[:, :f], (0, pad)), w_out[:, f:]], dim=1)
+    return x, w_nodes, w_out
+
+
+def _check_dtypes(x, edge_attr, *weights):
+    if not supported(x, edge_attr, *weights):
+        raise TypeError(
+            "the layer runs in float32, or in bfloat16 with a hidden width that is a multiple of 8, on the GPU; got "
+            f"x {x.dtype} on {x.device}, weights {[tuple(w.shape) for w in weights]} - there is no fallback path")
 
 
 @torch.compiler.disable
 def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=None) -> torch.Tensor:
+    _check_dtypes(x, edge_attr, w_nodes, w_edge, w_out)
     if x.dtype == torch.bfloat16:
         if halo is not None:
             raise NotImplementedError("the bfloat16 layer node has no halo exchange")
+        x, w_nodes, w_out = _pad_features(x, w_nodes, w_out)
         return _LayerFnBf16.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)
     return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph, halo)
+
+
+@torch.compiler.disable
+def egnn_layer_forward(x, pos, edge_attr, w_nodes, w_edge, w_out, w_pos, graph: MPGraph):
+    """(y [N, H], pos' [N, 3]) of one EGNN layer; pos and its gradient are float32 whatever the feature dtype."""
+    _check_dtypes(x, edge_attr, w_nodes, w_edge, w_out, w_pos)
+    if x.dtype == torch.bfloat16:
+        x, w_nodes, w_out = _pad_features(x, w_nodes, w_out)
+    return _EgnnLayerFn.apply(x, pos.float(), edge_attr, w_nodes, w_edge, w_out, w_pos, graph)

@@ -15,17 +15,10 @@ state_dict keys match (linear / linear_out; fused_linear / linear_3 / linear_out
 from __future__ import annotations
 
 import torch
-import torch.nn.functional as F
 from torch.nn import Linear
 
-from . import dense, layer_fn
+from . import layer_fn
 from .graph import graph_for
-from .ops import aggregate_fused, egnn_aggregate
-
-
-def _update(x: torch.Tensor, aggr: torch.Tensor, w_out: torch.Tensor) -> torch.Tensor:
-    """relu(linear_out(cat[x, aggr])) without materialising the cat (models/layers.py:69,140)."""
-    return dense.update(x, aggr, w_out)
 
 
 class MPNNLayerCat(torch.nn.Module):
@@ -41,11 +34,7 @@ class MPNNLayerCat(torch.nn.Module):
         graph = graph_for(edge_index, x.size(0))
         # [Wi ; Wj] stacked row-wise gives the [N, 2H] table (target half, source half) in one GEMM.
         w_nodes = torch.cat([w[:, :f], w[:, f:2 * f]], dim=0)
-        if layer_fn.supported(x, edge_attr, w, self.linear_out.weight):
-            return layer_fn.layer_forward(x, edge_attr, w_nodes, w[:, 2 * f:], self.linear_out.weight, graph)
-        ab = dense.project(x, w_nodes)
-        aggr = aggregate_fused(ab, edge_attr, w[:, 2 * f:], graph)
-        return _update(x, aggr, self.linear_out.weight)
+        return layer_fn.layer_forward(x, edge_attr, w_nodes, w[:, 2 * f:], self.linear_out.weight, graph)
 
 
 class MPNNLayerSum(torch.nn.Module):
@@ -58,12 +47,9 @@ class MPNNLayerSum(torch.nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         graph = graph_for(edge_index, x.size(0))
-        if layer_fn.supported(x, edge_attr, self.fused_linear.weight, self.linear_3.weight, self.linear_out.weight):
-            return layer_fn.layer_forward(x, edge_attr, self.fused_linear.weight, self.linear_3.weight,
-                                          self.linear_out.weight, graph)
-        ab = dense.project(x, self.fused_linear.weight)  # xs = ab[:, :H] (target), xt = ab[:, H:] (source)
-        aggr = aggregate_fused(ab, edge_attr, self.linear_3.weight, graph)
-        return _update(x, aggr, self.linear_out.weight)
+        # xs = AB[:, :H] (target half), xt = AB[:, H:] (source half) of the fused projection
+        return layer_fn.layer_forward(x, edge_attr, self.fused_linear.weight, self.linear_3.weight,
+                                      self.linear_out.weight, graph)
 
 
 class EGNNLayer(torch.nn.Module):
@@ -87,8 +73,5 @@ class EGNNLayer(torch.nn.Module):
 
     def forward(self, x, pos, edge_index, edge_attr):
         graph = graph_for(edge_index, x.size(0))
-        ab = dense.project(x, self.fused_linear.weight)
-        h = self.out_channels
-        aggr, pos_out = egnn_aggregate(ab[:, :h], ab[:, h:], edge_attr, self.linear_3.weight, pos.float(),
-                                       self.coord_linear.weight.view(-1), graph)
-        return _update(x, aggr, self.linear_out.weight), pos_out
+        return layer_fn.egnn_layer_forward(x, pos, edge_attr, self.fused_linear.weight, self.linear_3.weight,
+                                           self.linear_out.weight, self.coord_linear.weight.view(-1), graph)

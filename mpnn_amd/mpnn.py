@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn import Linear
 
-from .layers import MPNNLayerCat, MPNNLayerSum
+from .layers import EGNNLayer, MPNNLayerCat, MPNNLayerSum
 from .ops import global_mean_pool
 
 
@@ -64,3 +64,24 @@ class MPNN_QM9(_PooledMPNN):
 
 class MPNN_ModelNet(_PooledMPNN):
     pass
+
+
+class EGNN(torch.nn.Module):
+    """Graph-level model on EGNN layers, the shape of MPNN_QM9 / MPNN_ModelNet (models/mpnn.py:8-55, 104-151: layers ->
+    relu -> global_mean_pool -> Linear head) with the coordinates threaded through the layers.  The reference has no
+    EGNN; constructor arguments follow MPNN_QM9's, forward takes ``pos`` after ``x``:
+    forward(x, pos, edge_index, batch, edge_attr) -> logits [num_graphs, out_channels]
+    (``return_pos=True``: also the coordinates after the last layer, float32 [N, 3])."""
+
+    def __init__(self, in_channels, edge_channels, hidden_channels, out_channels, num_layers=2):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(
+            [EGNNLayer(in_channels if k == 0 else hidden_channels, edge_channels, hidden_channels)
+             for k in range(num_layers)])
+        self.output_layer = Linear(hidden_channels, out_channels)
+
+    def forward(self, x, pos, edge_index, batch, edge_attr, return_pos=False):
+        for layer in self.layers:
+            x, pos = layer(x, pos, edge_index, edge_attr)   # ends in a relu: the model loop's F.relu is the identity
+        out = self.output_layer(global_mean_pool(x, batch))
+        return (out, pos) if return_pos else out

@@ -198,79 +198,97 @@ def aggregate(A: torch.Tensor, B: torch.Tensor, edge_attr: torch.Tensor, We: tor
 # ----------------------------------------------------------------------------------------
 # EGNN: message pass + coordinate update in one edge pass (no reference counterpart)
 # ----------------------------------------------------------------------------------------
+def _run_egnn_forward(A, B, ea_s, We, pos, w_pos, graph: MPGraph):
+    """mpnn_egnn_fwd: (sum of messages [N, H], updated coordinates [N, 3])."""
+    lib = _lib.load()
+    N, H = A.shape
+    dev, dtype = A.device, A.dtype
+    csr = graph.by_dst
+    out = torch.empty((N, H), dtype=dtype, device=dev)
+    pos_out = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    part = graph.scratch("part_out", (csr.n_parts, H), torch.float32, dev) if csr.n_parts else None
+    small = graph.scratch("part_small", (csr.n_parts, 4), torch.float32, dev) if csr.n_parts else None
+    with _Timed("egnn_fwd", dev):
+        _lib.check(lib.mpnn_egnn_fwd(
+            _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(ea_s), ea_s.size(1), _lib.ptr(We),
+            _lib.ptr(w_pos), _lib.ptr(pos), _lib.ptr(pos), _lib.ptr(csr.col), _lib.ptr(csr.items), csr.n_items,
+            _lib.ptr(csr.split), csr.n_split, csr.n_parts, _lib.ptr(out), out.stride(0), _lib.ptr(pos_out),
+            _lib.ptr(part), _lib.ptr(small), N, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)),
+            "mpnn_egnn_fwd")
+    return out, pos_out
+
+
+def _run_egnn_backward(A, B, g, gp, ea_s, ea_t, We, w_pos, pos, graph: MPGraph, gA, gB):
+    """mpnn_egnn_bwd_dst + mpnn_egnn_bwd_src.  Fills gA and gB ([N, H] views with unit column stride) and returns
+    (gWe [H, Fe], g_pos [N, 3], g_wpos [H])."""
+    lib = _lib.load()
+    N, H = A.shape
+    Fe = ea_s.size(1)
+    dev, dtype = A.device, A.dtype
+    code, stream = _lib.dtype_code(dtype), _lib.stream_handle(dev)
+    scratch = graph.scratch("gwe", (lib.mpnn_bwd_scratch_floats(H, Fe),), torch.float32, dev)
+
+    csr = graph.by_dst
+    S = torch.empty((N,), dtype=torch.float32, device=dev)
+    g_wp = torch.empty((H,), dtype=dtype, device=dev)
+    part = graph.scratch("part_out", (csr.n_parts, H), torch.float32, dev) if csr.n_parts else None
+    small = graph.scratch("part_small", (csr.n_parts, 4), torch.float32, dev) if csr.n_parts else None
+    with _Timed("egnn_bwd_dst", dev):
+        _lib.check(lib.mpnn_egnn_bwd_dst(
+            _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(g), g.stride(0), _lib.ptr(gp),
+            _lib.ptr(ea_s), Fe, _lib.ptr(We), _lib.ptr(w_pos), _lib.ptr(pos), _lib.ptr(pos), _lib.ptr(csr.col),
+            _lib.ptr(csr.items), csr.n_items, _lib.ptr(csr.split), csr.n_split, csr.n_parts, _lib.ptr(gA),
+            gA.stride(0), _lib.ptr(S), _lib.ptr(g_wp), _lib.ptr(part), _lib.ptr(small), _lib.ptr(scratch), N, H,
+            code, stream), "mpnn_egnn_bwd_dst")
+
+    csr_t = graph.by_src
+    gps = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    gWe = torch.empty((H, Fe), dtype=dtype, device=dev)
+    part_t = graph.scratch("part_gB", (csr_t.n_parts, H), torch.float32, dev) if csr_t.n_parts else None
+    small_t = graph.scratch("part_small_t", (csr_t.n_parts, 4), torch.float32, dev) if csr_t.n_parts else None
+    with _Timed("egnn_bwd_src", dev):
+        _lib.check(lib.mpnn_egnn_bwd_src(
+            _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(g), g.stride(0), _lib.ptr(gp),
+            _lib.ptr(ea_t), Fe, _lib.ptr(We), _lib.ptr(w_pos), _lib.ptr(pos), _lib.ptr(pos), _lib.ptr(csr_t.col),
+            _lib.ptr(csr_t.items), csr_t.n_items, _lib.ptr(csr_t.split), csr_t.n_split, csr_t.n_parts,
+            _lib.ptr(gB), gB.stride(0), _lib.ptr(gps), _lib.ptr(gWe), _lib.ptr(part_t), _lib.ptr(small_t),
+            _lib.ptr(scratch), N, H, code, stream), "mpnn_egnn_bwd_src")
+    g_pos = torch.addcmul(gps, gp, (1.0 + S).unsqueeze(1))     # gp * (1 + S) + gps
+    return gWe, g_pos, g_wp
+
+
+def _prepare_egnn(A, B, edge_attr, We, pos, w_pos, graph: MPGraph):
+    if graph.num_dst != graph.num_src:
+        raise ValueError("egnn_aggregate needs one node set (num_dst == num_src)")
+    ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
+    N, H = A.shape
+    if pos.shape != (N, 3) or pos.dtype != torch.float32:
+        raise ValueError(f"pos must be float32 [{N}, 3], got {pos.dtype} {tuple(pos.shape)}")
+    if w_pos.shape != (H,) or w_pos.dtype != A.dtype:
+        raise ValueError(f"w_pos must have shape [{H}] and dtype {A.dtype}")
+    return ea_s, ea_t
+
+
 class _EgnnAggregate(torch.autograd.Function):
     """(A [N,H], B [N,H], edge_attr, We [H,Fe], pos [N,3] float, w_pos [H]) -> (aggr [N,H], pos' [N,3])."""
 
     @staticmethod
     def forward(ctx, A, B, edge_attr, We, pos, w_pos, graph):
-        lib = _lib.load()
-        if graph.num_dst != graph.num_src:
-            raise ValueError("egnn_aggregate needs one node set (num_dst == num_src)")
-        ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
-        N, H = A.shape
-        dev, dtype = A.device, A.dtype
-        if pos.shape != (N, 3) or pos.dtype != torch.float32:
-            raise ValueError(f"pos must be float32 [{N}, 3], got {pos.dtype} {tuple(pos.shape)}")
-        if w_pos.shape != (H,) or w_pos.dtype != dtype:
-            raise ValueError(f"w_pos must have shape [{H}] and dtype {dtype}")
+        ea_s, ea_t = _prepare_egnn(A, B, edge_attr, We, pos, w_pos, graph)
         We_c, pos_c, wp_c = We.contiguous(), pos.contiguous(), w_pos.contiguous()
-        csr = graph.by_dst
-        out = torch.empty((N, H), dtype=dtype, device=dev)
-        pos_out = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        part = graph.scratch("part_out", (csr.n_parts, H), torch.float32, dev) if csr.n_parts else None
-        small = graph.scratch("part_small", (csr.n_parts, 4), torch.float32, dev) if csr.n_parts else None
-        with _Timed("egnn_fwd", dev):
-            _lib.check(lib.mpnn_egnn_fwd(
-                _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(ea_s), ea_s.size(1), _lib.ptr(We_c),
-                _lib.ptr(wp_c), _lib.ptr(pos_c), _lib.ptr(pos_c), _lib.ptr(csr.col), _lib.ptr(csr.items), csr.n_items,
-                _lib.ptr(csr.split), csr.n_split, csr.n_parts, _lib.ptr(out), out.stride(0), _lib.ptr(pos_out),
-                _lib.ptr(part), _lib.ptr(small), N, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)),
-                "mpnn_egnn_fwd")
+        out, pos_out = _run_egnn_forward(A, B, ea_s, We_c, pos_c, wp_c, graph)
         ctx.save_for_backward(A, B, We_c, pos_c, wp_c, ea_s, ea_t)
         ctx.graph = graph
         return out, pos_out
 
     @staticmethod
     def backward(ctx, g, gp):
-        lib = _lib.load()
         A, B, We, pos, wp, ea_s, ea_t = ctx.saved_tensors
-        graph = ctx.graph
-        N, H = A.shape
-        Fe = ea_s.size(1)
-        dev, dtype = A.device, A.dtype
         g = torch.zeros_like(A) if g is None else g.contiguous()
         gp = torch.zeros_like(pos) if gp is None else gp.contiguous().float()
-        code, stream = _lib.dtype_code(dtype), _lib.stream_handle(dev)
-        scratch = graph.scratch("gwe", (lib.mpnn_bwd_scratch_floats(H, Fe),), torch.float32, dev)
-
-        csr = graph.by_dst
-        gA = torch.empty((N, H), dtype=dtype, device=dev)
-        S = torch.empty((N,), dtype=torch.float32, device=dev)
-        g_wp = torch.empty((H,), dtype=dtype, device=dev)
-        part = graph.scratch("part_out", (csr.n_parts, H), torch.float32, dev) if csr.n_parts else None
-        small = graph.scratch("part_small", (csr.n_parts, 4), torch.float32, dev) if csr.n_parts else None
-        with _Timed("egnn_bwd_dst", dev):
-            _lib.check(lib.mpnn_egnn_bwd_dst(
-                _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(g), g.stride(0), _lib.ptr(gp),
-                _lib.ptr(ea_s), Fe, _lib.ptr(We), _lib.ptr(wp), _lib.ptr(pos), _lib.ptr(pos), _lib.ptr(csr.col),
-                _lib.ptr(csr.items), csr.n_items, _lib.ptr(csr.split), csr.n_split, csr.n_parts, _lib.ptr(gA),
-                gA.stride(0), _lib.ptr(S), _lib.ptr(g_wp), _lib.ptr(part), _lib.ptr(small), _lib.ptr(scratch), N, H,
-                code, stream), "mpnn_egnn_bwd_dst")
-
-        csr_t = graph.by_src
-        gB = torch.empty((N, H), dtype=dtype, device=dev)
-        gps = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        gWe = torch.empty((H, Fe), dtype=dtype, device=dev)
-        part_t = graph.scratch("part_gB", (csr_t.n_parts, H), torch.float32, dev) if csr_t.n_parts else None
-        small_t = graph.scratch("part_small_t", (csr_t.n_parts, 4), torch.float32, dev) if csr_t.n_parts else None
-        with _Timed("egnn_bwd_src", dev):
-            _lib.check(lib.mpnn_egnn_bwd_src(
-                _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(g), g.stride(0), _lib.ptr(gp),
-                _lib.ptr(ea_t), Fe, _lib.ptr(We), _lib.ptr(wp), _lib.ptr(pos), _lib.ptr(pos), _lib.ptr(csr_t.col),
-                _lib.ptr(csr_t.items), csr_t.n_items, _lib.ptr(csr_t.split), csr_t.n_split, csr_t.n_parts,
-                _lib.ptr(gB), gB.stride(0), _lib.ptr(gps), _lib.ptr(gWe), _lib.ptr(part_t), _lib.ptr(small_t),
-                _lib.ptr(scratch), N, H, code, stream), "mpnn_egnn_bwd_src")
-        g_pos = gp * (1.0 + S).unsqueeze(1) + gps
+        gA, gB = torch.empty_like(A, memory_format=torch.contiguous_format), torch.empty_like(
+            B, memory_format=torch.contiguous_format)
+        gWe, g_pos, g_wp = _run_egnn_backward(A, B, g, gp, ea_s, ea_t, We, wp, pos, ctx.graph, gA, gB)
         return gA, gB, None, gWe, g_pos, g_wp, None
 
 

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from . import dense, layer_fn, ops
 from .graph import make_graph
-from .layers import MPNNLayerCat, MPNNLayerSum, _update
+from .layers import MPNNLayerCat, MPNNLayerSum
 
 
 def dst_range_bounds(dst: torch.Tensor, num_nodes: int, world: int) -> list:
@@ -164,8 +164,11 @@ def halo_all_gather(b_local: torch.Tensor, pg: PartitionedGraph, group=None) -> 
 
 
 def partitioned_layer(layer, x_local: torch.Tensor, pg: PartitionedGraph, edge_attr_local: torch.Tensor,
-                      group=None, aggregate_fn=None) -> torch.Tensor:
-    """One MPNN layer on the local destination range (same arithmetic as layer.forward on the whole graph)."""
+                      group=None, aggregate_fn=None, dense_fns=None) -> torch.Tensor:
+    """One MPNN layer on the local destination range (same arithmetic as layer.forward on the whole graph).
+
+    ``aggregate_fn`` / ``dense_fns`` = (project, update) replace the HIP operators by stand-ins with the same
+    signatures; they exist for the CPU rehearsals of the exchange logic (the kernels need a GPU)."""
     if isinstance(layer, MPNNLayerSum):
         w_nodes, w_edge = layer.fused_linear.weight, layer.linear_3.weight
     elif isinstance(layer, MPNNLayerCat):
@@ -180,18 +183,21 @@ def partitioned_layer(layer, x_local: torch.Tensor, pg: PartitionedGraph, edge_a
         # the whole layer as one autograd node with the two exchanges inside
         return layer_fn.layer_forward(x_local, edge_attr_local, w_nodes, w_edge, w_out, pg.graph, Halo(pg, group))
     aggregate_fn = aggregate_fn or ops.aggregate
-    ab = dense.project(x_local, w_nodes)
+    project, update = dense_fns or (dense.project, dense.update)
+    ab = project(x_local, w_nodes)
     h = ab.size(1) // 2
     b_all = halo_all_gather(ab[:, h:], pg, group)
     aggr = aggregate_fn(ab[:, :h], b_all, edge_attr_local, w_edge, pg.graph)
-    return _update(x_local, aggr, layer.linear_out.weight)
+    return update(x_local, aggr, layer.linear_out.weight)
 
 
-def partitioned_model(model, x_local, pg: PartitionedGraph, edge_attr_local, group=None, aggregate_fn=None):
+def partitioned_model(model, x_local, pg: PartitionedGraph, edge_attr_local, group=None, aggregate_fn=None,
+                      dense_fns=None):
     """MPNN.forward (reference models/mpnn.py:86-101) on the local range; returns the local rows of the logits."""
     x = x_local
     for layer in model.layers:
-        x = partitioned_layer(layer, x, pg, edge_attr_local, group, aggregate_fn)   # ends in a relu: F.relu(x) is the identity
+        # every layer ends in a relu: the F.relu(x) of the model loop is the identity
+        x = partitioned_layer(layer, x, pg, edge_attr_local, group, aggregate_fn, dense_fns)
     return model.output_layer(x)
 
 

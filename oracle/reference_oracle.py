@@ -246,6 +246,30 @@ def egnn_layer(a, b, edge_attr, w_edge, pos, w_pos, edge_index):
     return aggr, pos + scatter_sum(rel * s, edge_index, pos.size(0))
 
 
+def egnn_full_layer(x, pos, edge_index, edge_attr, w_fused, w_edge, w_out, w_pos):
+    """Whole EGNN layer: MPNNLayerSum's projection and update (models/layers.py:104-110,140) around egnn_layer.
+    Returns (relu(linear_out([x | aggr])), pos')."""
+    fused = F.linear(x, w_fused)
+    xs, xt = fused.chunk(2, dim=1)
+    aggr, pos_out = egnn_layer(xs, xt, edge_attr, w_edge, pos, w_pos.view(-1), edge_index)
+    return update(x, aggr, w_out), pos_out
+
+
+def egnn_model_forward(params: dict, x, pos, edge_index, edge_attr, batch):
+    """Stack of EGNN layers -> relu -> global_mean_pool -> Linear head, the shape of models/mpnn.py:38-55 with the
+    coordinates threaded through.  ``params``: ``layers.{k}.{fused_linear,linear_3,linear_out,coord_linear}.weight``
+    and ``output_layer.{weight,bias}``.  Returns (logits, pos after the last layer)."""
+    k = 0
+    while f"layers.{k}.linear_out.weight" in params:
+        x, pos = egnn_full_layer(x, pos, edge_index, edge_attr, params[f"layers.{k}.fused_linear.weight"],
+                                 params[f"layers.{k}.linear_3.weight"], params[f"layers.{k}.linear_out.weight"],
+                                 params[f"layers.{k}.coord_linear.weight"])
+        x = F.relu(x)
+        k += 1
+    x = global_mean_pool(x, batch)
+    return F.linear(x, params["output_layer.weight"], params["output_layer.bias"]), pos
+
+
 # ----------------------------------------------------------------------------
 # mini-batch collation (torch_geometric DataLoader semantics)
 # ----------------------------------------------------------------------------

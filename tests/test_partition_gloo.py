@@ -27,6 +27,14 @@ def cpu_aggregate(a, b, edge_attr, w_edge, graph):
     return a.new_zeros(num_dst, a.size(1)).index_add_(0, ei[1], msg)
 
 
+def cpu_project(x, w):
+    return torch.nn.functional.linear(x, w)
+
+
+def cpu_update(x, aggr, w_out):
+    return torch.relu(torch.nn.functional.linear(torch.cat([x, aggr], 1), w_out))
+
+
 def make_problem(mode):
     gen = torch.Generator().manual_seed(17)
     n, e, f_in, fe, h = 120, 1500, 10, 4, 16
@@ -50,7 +58,8 @@ def _worker(rank, world, port, mode, out_dir):
         n, ei, x, ea, y, model = make_problem(mode)
         pg = PartitionedGraph(ei, n, rank, world, graph_factory=cpu_graph)
         x_loc = pg.local_rows(x).clone().requires_grad_(True)
-        logits = partitioned_model(model, x_loc, pg, pg.local_edges(ea), aggregate_fn=cpu_aggregate)
+        logits = partitioned_model(model, x_loc, pg, pg.local_edges(ea), aggregate_fn=cpu_aggregate,
+                                   dense_fns=(cpu_project, cpu_update))
         # sum-reduced loss so that the global loss is the sum of the local ones
         loss = torch.nn.functional.cross_entropy(logits, pg.local_rows(y), reduction="sum")
         loss.backward()
