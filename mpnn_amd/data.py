@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import CHUNK, CSR, MPGraph, register_graph
+from .graph import CHUNK, CSR, MPGraph, forget_graph, register_graph
 from .ops import register_pool
 
 
@@ -29,6 +29,7 @@ class Batch:
         self.num_graphs = num_graphs
         self.num_nodes = x.size(0)
         self._parts = None
+        self._graph = None     # MPGraph over the structures mpnn_collate wrote (stores whose rows are never split)
         self.capacity = None   # (nodes, edges) of a padded batch, see GraphStore.collate
 
     def to(self, device):
@@ -165,6 +166,10 @@ class GraphStore:
                 raise ValueError("collate(out=...) needs a batch of identical size (or a padded batch)")
             out._parts["slots"].copy_(torch.from_numpy(table), non_blocking=True)
             self._launch(out._parts, b, n, e, out.capacity)
+            # The launch rewrote edge_index, edge_attr and batch through raw pointers, which leaves their version
+            # counters (the caches' staleness test) unchanged: put the structures that were rewritten with them
+            # back under their keys, or drop what was derived from the old contents.
+            self._register(out, n)
             return out
         if capacity is not None:
             n_out, e_out = int(capacity[0]), int(capacity[1])
@@ -204,16 +209,28 @@ class GraphStore:
                 c.items, c.split = parts["items_" + sfx], None
                 c.n_items, c.n_parts, c.n_split = n_out, 0, 0
                 views.append(c)
-            g = MPGraph.from_parts(views[0], views[1], parts["tpos"])
-            g.seed_edge_attr(parts["ea"], parts["ea_dst"], parts["ea_src"])
-            register_graph(parts["edge_index"], n_out, g)
+            res._graph = MPGraph.from_parts(views[0], views[1], parts["tpos"])
         if self._iota.numel() < n_out:
             self._iota = torch.arange(max(n_out, 2 * self._iota.numel()), **i32)
-        if capacity is not None:   # graphs 0 .. b-1 and the padding graph b
+        self._register(res, n)
+        return res
+
+    def _register(self, batch: Batch, n: int) -> None:
+        """Makes the layers and the pooling find the structures mpnn_collate just wrote for ``batch`` (after a
+        first assembly and after every refill through ``out=``)."""
+        parts, b = batch._parts, batch.num_graphs
+        n_out = parts["x"].size(0)
+        if batch._graph is not None:
+            batch._graph.seed_edge_attr(parts["ea"], parts["ea_dst"], parts["ea_src"])
+            register_graph(parts["edge_index"], n_out, batch._graph)
+        else:
+            # rows too long for one work item each: the layers build the general structure from edge_index on
+            # first use - never reuse one built from the buffer's earlier contents
+            forget_graph(parts["edge_index"])
+        if batch.capacity is not None:   # graphs 0 .. b-1 and the padding graph b
             register_pool(parts["batch"], b + 1, parts["pool_rowptr"], self._iota[:n_out])
         else:
             register_pool(parts["batch"], b, parts["slots"][0], self._iota[:n])
-        return res
 
     def _launch(self, t: dict, b: int, n: int, e: int, capacity=None) -> None:
         ga = self.graph_all

@@ -287,5 +287,14 @@ def register_graph(edge_index: torch.Tensor, num_nodes: int, g: MPGraph) -> None
         _CACHE.popitem(last=False)
 
 
+def forget_graph(edge_index: torch.Tensor) -> None:
+    """Drops every cache entry built for the storage of ``edge_index``.  For callers that rewrite an edge list
+    through raw device pointers: such writes do not bump the tensor's version counter, so an entry built from the
+    earlier contents would still match."""
+    ptr = edge_index.data_ptr()
+    for key in [k for k in _CACHE if k[0] == ptr]:
+        del _CACHE[key]
+
+
 def clear_cache() -> None:
     _CACHE.clear()

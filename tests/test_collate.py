@@ -279,3 +279,75 @@ def test_captured_batch_step_trains_like_the_eager_loop():
     for pa, pb in zip(models[0].parameters(), models[1].parameters()):
         assert_close(pb, pa.detach().double().cpu(), 1e-3, what="weights")
     clear_cache()
+
+
+def _hub_store(dev):
+    """Graphs of identical size whose node 0 receives an edge from every other node of the graph and a second one
+    from most of them (in-degree 70 + 40 > 64, so rows are split and the store cannot register its own structure)."""
+    from mpnn_amd.data import GraphStore
+    gen = torch.Generator().manual_seed(11)
+    n_graphs, per = 12, 71
+    srcs, dsts = [], []
+    for g in range(n_graphs):
+        base = g * per
+        others = torch.arange(1, per) + base
+        extra = others[torch.randperm(per - 1, generator=gen)[:40]]
+        back = others[torch.randperm(per - 1, generator=gen)[:30]]
+        srcs += [others, extra, torch.full((30,), base)]
+        dsts += [torch.full((per - 1,), base), torch.full((40,), base), back]
+    ei = torch.stack([torch.cat(srcs), torch.cat(dsts)])
+    e_per = (per - 1) + 40 + 30
+    x = torch.rand(n_graphs * per, 11, generator=gen)
+    ea = torch.rand(ei.size(1), 4, generator=gen)
+    y = torch.randn(n_graphs, 19, generator=gen)
+    node_ptr = torch.arange(n_graphs + 1) * per
+    edge_ptr = torch.arange(n_graphs + 1) * e_per
+    return GraphStore(x.to(dev), ei.to(dev), ea.to(dev), node_ptr, edge_ptr, y=y.to(dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["hub-store (general graph builder)", "fused store after clear_cache", "fused store, many batches between"])
+def test_refilled_batch_uses_the_structure_of_its_new_contents(kind):
+    """collate(ids, out=batch) rewrites a batch through raw device pointers (no version bump): the layers must
+    never run on an index structure or sorted edge attributes derived from the earlier contents."""
+    from mpnn_amd import MPNN_QM9
+    from mpnn_amd.graph import clear_cache
+    dev = torch.device("cuda:0")
+    clear_cache()
+    if kind.startswith("hub"):
+        store = _hub_store(dev)
+        assert not store.fused
+        first, second = [0, 1, 2, 3], [7, 5, 11, 9]
+    else:
+        store, _ = _store_and_cpu("modelnet", 48)        # equal-size clouds: any ids refill the same buffers
+        assert store.fused
+        first, second = [0, 1, 2, 3], [40, 7, 33, 21]
+    torch.manual_seed(0)
+    model = MPNN_QM9(store.x.size(1), store.edge_attr.size(1), 64, 19, num_layers=2, mode="sum").to(dev)
+
+    def run(b):
+        model.zero_grad()
+        out = model(b.x, b.edge_index, b.batch, b.edge_attr)
+        (out * out).sum().backward()
+        return out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    batch = store.collate(first)
+    run(batch)                                            # builds / finds the structure of the first contents
+    if kind == "fused store after clear_cache":
+        clear_cache()
+    if kind == "fused store, many batches between":
+        for k in range(12):                               # more than the graph cache holds
+            run(store.collate([k, k + 1, k + 2, k + 3]))
+    store.collate(second, out=batch)
+    got = run(batch)
+    if kind == "fused store after clear_cache":           # ... and once more, now from whatever that run left behind
+        store.collate(first, out=batch)
+        run(batch)
+        store.collate(second, out=batch)
+        got = run(batch)
+    clear_cache()
+    want = run(store.collate(second))
+    assert torch.equal(got[0], want[0])
+    for k in want[1]:
+        assert_close(got[1][k], want[1][k], 1e-6, what=k)
+    clear_cache()
