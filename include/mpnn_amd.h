@@ -405,7 +405,9 @@ int32_t mpnn_segment_mean_bwd(const void* gout, int64_t ldg, const int32_t* rowp
  * mpnn_masked_ce: mean cross-entropy over the rows with mask != 0 (mask == NULL: every row), what the
  * reference computes as F.cross_entropy(out[data.train_mask], data.y[data.train_mask])
  * (training/train.py:47 with experiments/flickr_exp.py:31).
- *   logits [n, c] float, labels [n] int64, mask [n] bytes (torch.bool storage)
+ *   logits [n, c] float, labels [n] int64, mask [n] bytes (torch.bool storage); a label of -100 (F.cross_entropy's
+ *   default ignore_index) leaves its row out of the sum, the count and the gradient; any other label outside
+ *   [0, c), which torch rejects, makes the loss NaN
  *   grad   [n, c]  softmax - onehot on masked rows, 0 elsewhere - NOT yet divided by the row count
  *   result [2]     { loss, 1 / number of masked rows }   (the gradient of the loss is grad * result[1])
  *   scratch        mpnn_masked_ce_scratch_floats() floats

@@ -151,6 +151,12 @@ def ptr(t) -> int | None:
 
 
 def stream_handle(device) -> int:
+    """The current stream of ``device``, which must be the current device: the library launches on the device that
+    is current in the calling thread (wrap calls on another GPU's tensors in ``torch.cuda.device(...)``)."""
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if index != torch.cuda.current_device():
+        raise MpnnError(f"tensors live on cuda:{index} but cuda:{torch.cuda.current_device()} is the current device; "
+                        "run the call under torch.cuda.device(tensor.device)")
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -1085,9 +1085,15 @@ static bool nt_presplit() {
 template <bool MASKED, bool PAIR_K>
 static void launch_tn_pair(dim3 grid, const TnArgs& a, hipStream_t stream) {
   // more than 64 KiB of dynamic LDS needs the attribute; set once per kernel (the call is far slower than a launch)
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_tr2<MASKED, PAIR_K>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTr2Stage);
-  (void)attr;
+  // the attribute belongs to the kernel's image on ONE device: once per kernel and device, with that device current
+  static bool done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_tr2<MASKED, PAIR_K>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTr2Stage) == hipSuccess)
+      __atomic_store_n(&done[dev], true, __ATOMIC_RELEASE);
+    // on failure the launch below fails for want of LDS and the caller's launch check reports it
+  }
   k_gemm_tn_tr2<MASKED, PAIR_K><<<grid, 2 * kBlock, 2 * kTr2Stage, stream>>>(a);
 }
 

@@ -27,7 +27,9 @@ __global__ void __launch_bounds__(kBlock) k_masked_ce(const float* __restrict__ 
   for (int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x; row < n; row += (int64_t)gridDim.x * kBlock) {
     const float* x = logits + row * ld;
     float* g = grad + row * ldg;
-    const bool on = mask ? mask[row] != 0 : true;
+    const int64_t y = labels[row];
+    // F.cross_entropy's default ignore_index: such a row adds nothing to the sum, the count or the gradient
+    const bool on = (mask ? mask[row] != 0 : true) && y != -100;
     if (!on) {
       for (int j = 0; j < c; ++j) g[j] = 0.f;
       continue;
@@ -37,10 +39,10 @@ __global__ void __launch_bounds__(kBlock) k_masked_ce(const float* __restrict__ 
     float se = 0.f;
     for (int j = 0; j < c; ++j) se += expf(x[j] - mx);
     const float lse = logf(se) + mx;
-    const int64_t y = labels[row];
     const float inv = 1.f / se;
     for (int j = 0; j < c; ++j) g[j] = expf(x[j] - mx) * inv - (j == y ? 1.f : 0.f);
-    loss += (y >= 0 && y < c) ? lse - x[y] : 0.f;
+    // any other label outside [0, c) is an error in torch; here it turns the loss into NaN instead of passing unseen
+    loss += (y >= 0 && y < c) ? lse - x[y] : __builtin_nanf("");
     cnt += 1.f;
   }
   s_loss[threadIdx.x] = loss;

@@ -236,8 +236,9 @@ class MPGraph:
         return self._ea_sorted
 
     def scratch(self, name: str, shape, dtype, device) -> torch.Tensor:
-        """Reusable scratch slabs (partial sums of split rows, gradient partials)."""
-        key = (name, tuple(shape), dtype)
+        """Reusable scratch slabs (partial sums of split rows, gradient partials), one set per stream: calls on
+        one stream reuse them in stream order, calls on different streams never share them."""
+        key = (name, tuple(shape), dtype, torch.cuda.current_stream(device).cuda_stream)
         buf = self._scratch.get(key)
         if buf is None:
             buf = torch.empty(shape, dtype=dtype, device=device)

@@ -135,9 +135,13 @@ class CapturedBatchStep:
         self.model, self.optimizer, self.loss_fn, self.store = model, optimizer, loss_fn, store
         self.batch_size, self.features = int(batch_size), features
         self.loss_of = loss_of or (lambda out, b: loss_fn(out[0], b.y[0]))
+        if not (hasattr(optimizer, "state_snapshot") and hasattr(optimizer, "state_restore")):
+            raise TypeError("CapturedBatchStep runs warm-up steps before recording and must put the optimizer back: "
+                            "it needs state_snapshot() / state_restore() (mpnn_amd.optim.FlatAdam has them)")
         self.capacity = store.capacity_for(self.batch_size)
         self.batch = None
         self.captured = None
+        self.graph = None      # the MPGraph whose scratch buffers the recorded launches write to
 
     def _step(self, b):
         self.optimizer.zero_grad()
@@ -156,13 +160,13 @@ class CapturedBatchStep:
             self.batch = self.store.collate(ids, capacity=self.capacity)
             # the warm-up steps of the capture would train on this batch: record on a copy of the state
             state = [p.detach().clone() for p in self.model.parameters()]
-            opt_state = self.optimizer.state_snapshot() if hasattr(self.optimizer, "state_snapshot") else None
+            opt_state = self.optimizer.state_snapshot()
             self.captured = CapturedStep(lambda: self._step(self.batch), warmup=2)
+            self.graph = self.batch._graph       # pinned here, not only through the graph cache's 8 entries
             with torch.no_grad():
                 for p, s0 in zip(self.model.parameters(), state):
                     p.copy_(s0)
-            if opt_state is not None:
-                self.optimizer.state_restore(opt_state)
+            self.optimizer.state_restore(opt_state)
         else:
             self.store.collate(ids, out=self.batch)
         return self.captured.replay()

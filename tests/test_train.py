@@ -55,6 +55,29 @@ def test_masked_ce_kernel(n, c, frac):
 
 
 @pytest.mark.gpu
+def test_masked_ce_kernel_label_handling():
+    """A label of -100 is F.cross_entropy's default ignore_index: the row leaves the sum, the count and the
+    gradient.  Any other label outside [0, c) is an error in torch; the fused loss turns NaN instead of hiding it."""
+    from mpnn_amd.loss import masked_cross_entropy
+    g = torch.Generator().manual_seed(3)
+    out = (torch.randn(200, 7, generator=g) * 2).requires_grad_(True)
+    y = torch.randint(0, 7, (200,), generator=g)
+    y[::9] = -100
+    mask = torch.rand(200, generator=g) < 0.6
+    want = F.cross_entropy(out[mask].double(), y[mask])
+    (gw,) = torch.autograd.grad(want, out)
+    xo = out.detach().cuda().requires_grad_(True)
+    got = masked_cross_entropy(xo, y.cuda(), mask.cuda())
+    (gg,) = torch.autograd.grad(got, xo)
+    assert_close(got, want, 1e-5, what="loss with ignored rows")
+    assert_close(gg, gw, 1e-5, what="grad with ignored rows")
+    assert float(gg[::9].abs().max()) == 0.0
+    y[1] = 7
+    mask[1] = True
+    assert torch.isnan(masked_cross_entropy(xo, y.cuda(), mask.cuda()))
+
+
+@pytest.mark.gpu
 def test_flat_adam_follows_torch_adam():
     from mpnn_amd import MPNN
     from mpnn_amd.optim import FlatAdam
