@@ -10,19 +10,19 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for W in powerlaw flickr modelnet qm9; do
   echo "== $W kernel trace"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$W -o $W --output-format csv -- \
-      python3 bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_${W}_f32.json 2> gpurun_out/prof_$W.err || exit 1
+      python3 bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-model-step > $O/${R}_bench_${W}_f32.json 2> gpurun_out/prof_$W.err || exit 1
   cp gpurun_out/prof_$W/${W}_kernel_stats.csv $O/${R}_bench_${W}_f32_kernel_stats.csv || exit 1
 done
 echo "== powerlaw bf16 kernel trace"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_powerlaw_bf16 -o powerlaw --output-format csv -- \
-    python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline > $O/${R}_bench_powerlaw_bf16.json 2> gpurun_out/prof_powerlaw_bf16.err || exit 1
+    python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-model-step > $O/${R}_bench_powerlaw_bf16.json 2> gpurun_out/prof_powerlaw_bf16.err || exit 1
 cp gpurun_out/prof_powerlaw_bf16/powerlaw_kernel_stats.csv $O/${R}_bench_powerlaw_bf16_kernel_stats.csv || exit 1
 SPECS=""
 for W in powerlaw flickr; do
   for C in FETCH_SIZE WRITE_SIZE; do
     echo "== $W pmc $C"
     timeout -s KILL 300 rocprofv3 --pmc $C -d gpurun_out/pmc_${W}_$C -o p --output-format csv -- \
-        python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> gpurun_out/pmc_${W}_$C.err || exit 1
+        python3 bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-verify --no-model-step > /dev/null 2> gpurun_out/pmc_${W}_$C.err || exit 1
   done
   SPECS="$SPECS $W=gpurun_out/pmc_${W}_FETCH_SIZE/p_counter_collection.csv,gpurun_out/pmc_${W}_WRITE_SIZE/p_counter_collection.csv"
 done
