@@ -1,4 +1,4 @@
-"""One autograd node for a whole MPNN layer (float32, GPU).
+"""One autograd node for a whole MPNN layer (GPU; float32, or bfloat16 storage with float32 accumulation).
 
 Forward and backward of MPNNLayerSum / MPNNLayerCat (reference models/layers.py:25-69 and :91-140) as a fixed
 sequence of library calls, so that nothing between them needs an elementwise pass:
@@ -20,114 +20,102 @@ from .dense import gemm_nt, gemm_nt_bf16, gemm_tn, gemm_tn_bf16
 from .graph import MPGraph
 
 
-class _LayerFn(torch.autograd.Function):
-    """``halo`` (partitioned graphs, see partition.Halo): the rows of x are this rank's destination range, the
-    source-side projection is exchanged across the ranks before the edge pass and its gradient summed back to the
-    owners after the backward edge pass; everything else is local."""
-
-    @staticmethod
-    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=None):
-        x = x if x.is_contiguous() else x.contiguous()
-        f = x.size(1)
-        h = w_out.size(0)
-        ab = gemm_nt(x, w_nodes)
-        a = ab[:, :h]
-        b = ab[:, h:] if halo is None else halo.gather(ab[:, h:])
-        ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
-        w_edge_c = w_edge.contiguous()
-        want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
-        aggr, cnt, maskbits = ops._run_forward(a, b, ea_s, w_edge_c, graph.by_dst, graph, want)
-        y = gemm_nt(x, w_out[:, :f], aggr, w_out[:, f:], relu=True)
-        if want:
-            if maskbits is not None:
-                graph.tpos
-            # the gathered source table is only read again by the recomputing backward
-            b_all = b if (halo is not None and maskbits is None) else None
-            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge_c, w_out, b_all)
-            ctx.graph, ctx.halo = graph, halo
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, b_all = ctx.saved_tensors
-        graph, halo = ctx.graph, ctx.halo
-        f = x.size(1)
-        h = w_out.size(0)
-        gy = gy if gy.is_contiguous() else gy.contiguous()
-        wt_out = w_out.t().contiguous()               # [F+H, H]
-        g_ab = torch.empty_like(ab)
-        g_wout = torch.empty_like(w_out) if ctx.needs_input_grad[4] else None
-        g, m = gy, y
-        # gz = gy * [y > 0] leaves the first weight-gradient GEMM as a by-product (written in whole 512-byte rows),
-        # so the four GEMMs after it read one matrix instead of (gy, y); needs 16-byte aligned rows
-        if g_wout is not None and h % 4 == 0 and f % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, y, x, aggr)):
-            gz = torch.empty_like(gy)
-            gemm_tn(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)   # both halves of gW_out in one pass over gy
-            g, m = gz, None
-        elif g_wout is not None:
-            gemm_tn(gy, x, mask=y, out=g_wout, x2=aggr)
-        ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt, out2=g_ab[:, :h])
-        if halo is None:
-            g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
-        else:   # gradient for every source row this rank's edges read, then summed back to the owners
-            gb_all = torch.empty((graph.num_src, h), dtype=ab.dtype, device=ab.device)
-            g_we = ops._run_backward_src(ab[:, :h], b_all, ga, ea_t, w_edge, graph.by_src, graph, gb_all, maskbits)
-            halo.scatter_sum(gb_all, g_ab[:, h:])
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = gemm_nt(g, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=m)
-        g_wn = gemm_tn(g_ab, x) if ctx.needs_input_grad[2] else None
-        return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None, None
-
-
-class _LayerFnBf16(torch.autograd.Function):
-    """The same node for bfloat16 models: bf16 storage, float32 accumulation.  The products with a huge row count
-    run on mpnn_gemm_nt_bf16, the three weight-gradient products (reductions over the rows) on mpnn_gemm_tn_bf16,
-    the first of which also leaves the relu-masked upstream gradient."""
-
-    @staticmethod
-    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
-        f = x.size(1)
-        h = w_out.size(0)
-        ab = gemm_nt_bf16(x, w_nodes.contiguous())
-        a, b = ab[:, :h], ab[:, h:]
-        ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
-        w_edge_c = w_edge.contiguous()
-        want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
-        aggr, cnt, maskbits = ops._run_forward(a, b, ea_s, w_edge_c, graph.by_dst, graph, want)
-        wt = w_out.t().contiguous()                   # [F+H, H]; its transpose halves are needed both ways
+def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: bool, halo=None):
+    """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea_t, b_all); cnt / maskbits are
+    None when ``want`` (a backward will follow) is false or no mask layout exists, b_all is the gathered source
+    table when a partitioned layer's backward will need it again."""
+    bf = x.dtype == torch.bfloat16
+    x = x if x.is_contiguous() else x.contiguous()
+    f = x.size(1)
+    h = w_out.size(0)
+    ab = gemm_nt_bf16(x, w_nodes.contiguous()) if bf else gemm_nt(x, w_nodes)
+    a = ab[:, :h]
+    b = ab[:, h:] if halo is None else halo.gather(ab[:, h:])
+    ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
+    aggr, cnt, maskbits = ops._run_forward(a, b, ea_s, w_edge.contiguous(), graph.by_dst, graph, want)
+    if bf:
         y = gemm_nt_bf16(x, w_out[:, :f].contiguous(), aggr, w_out[:, f:].contiguous(), relu=True)
-        if want:
-            if maskbits is not None:
-                graph.tpos
-            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge_c, wt)
-            ctx.graph = graph
-        return y
+    else:
+        y = gemm_nt(x, w_out[:, :f], aggr, w_out[:, f:], relu=True)
+    if want and maskbits is not None:
+        graph.tpos                       # built once per graph, outside the backward
+    # the gathered source table is only read again by the recomputing backward
+    b_all = b if (want and halo is not None and maskbits is None) else None
+    return y, ab, aggr, cnt, maskbits, ea_t, b_all
 
-    @staticmethod
-    def backward(ctx, gy):
-        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, wt = ctx.saved_tensors
-        graph = ctx.graph
-        f = x.size(1)
-        h = wt.size(1)
-        gy = gy if gy.is_contiguous() else gy.contiguous()
-        if gy.data_ptr() % 16:
-            gy = gy.clone()                           # a view into a larger buffer: fresh allocations are aligned
-        g_ab = torch.empty_like(ab)
-        g_wout = torch.empty((h, f + h), dtype=gy.dtype, device=gy.device) if ctx.needs_input_grad[4] else None
+
+def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, graph: MPGraph, needs,
+                  halo=None, b_all=None):
+    """The backward sequence.  ``needs`` = (x, w_nodes, w_edge, w_out) gradients wanted; returns them in that order
+    (None where not wanted)."""
+    need_x, need_wn, need_we, need_wout = needs
+    bf = x.dtype == torch.bfloat16
+    f = x.size(1)
+    h = w_out.size(0)
+    w_edge = w_edge.contiguous()
+    gy = gy if gy.is_contiguous() else gy.contiguous()
+    if gy.data_ptr() % 16:
+        gy = gy.clone()                               # a view into a larger buffer: fresh allocations are aligned
+    wt_out = w_out.t().contiguous()                   # [F+H, H]
+    g_ab = torch.empty_like(ab)
+    g_wout = torch.empty((h, f + h), dtype=gy.dtype, device=gy.device) if need_wout else None
+    if bf:
         # gz = gy * [y > 0] is a by-product of the first weight-gradient product (whole 256-byte rows)
         if g_wout is not None:
             gz = torch.empty_like(gy)
             gemm_tn_bf16(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)   # both halves of gW_out in one pass over gy
         else:
             gz = torch.ops.aten.threshold_backward(gy, y, 0)
-        ga = gemm_nt_bf16(gz, wt[f:], emul=cnt, out2=g_ab[:, :h])
+        ga = gemm_nt_bf16(gz, wt_out[f:], emul=cnt, out2=g_ab[:, :h])
         g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            gx = gemm_nt_bf16(gz, wt[:f], g_ab, w_nodes.t().contiguous())
-        g_wn = gemm_tn_bf16(g_ab, x) if ctx.needs_input_grad[2] else None
-        return gx, None, g_wn, g_we if ctx.needs_input_grad[3] else None, g_wout, None
+        gx = gemm_nt_bf16(gz, wt_out[:f], g_ab, w_nodes.t().contiguous()) if need_x else None
+        g_wn = gemm_tn_bf16(g_ab, x) if need_wn else None
+        return gx, g_wn, g_we if need_we else None, g_wout
+    g, m = gy, y
+    # gz = gy * [y > 0] leaves the first weight-gradient GEMM as a by-product (written in whole 512-byte rows),
+    # so the four GEMMs after it read one matrix instead of (gy, y); needs 16-byte aligned rows
+    if g_wout is not None and h % 4 == 0 and f % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in (gy, y, x, aggr)):
+        gz = torch.empty_like(gy)
+        gemm_tn(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)   # both halves of gW_out in one pass over gy
+        g, m = gz, None
+    elif g_wout is not None:
+        gemm_tn(gy, x, mask=y, out=g_wout, x2=aggr)
+    ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt, out2=g_ab[:, :h])
+    if halo is None:
+        g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
+    else:   # gradient for every source row this rank's edges read, then summed back to the owners
+        gb_all = torch.empty((graph.num_src, h), dtype=ab.dtype, device=ab.device)
+        g_we = ops._run_backward_src(ab[:, :h], b_all, ga, ea_t, w_edge, graph.by_src, graph, gb_all, maskbits)
+        halo.scatter_sum(gb_all, g_ab[:, h:])
+    gx = gemm_nt(g, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=m) if need_x else None
+    g_wn = gemm_tn(g_ab, x) if need_wn else None
+    return gx, g_wn, g_we if need_we else None, g_wout
+
+
+class _LayerFn(torch.autograd.Function):
+    """The layer as one autograd node, float32 or bfloat16 storage (float32 accumulation throughout).
+
+    ``halo`` (partitioned graphs, see partition.Halo): the rows of x are this rank's destination range, the
+    source-side projection is exchanged across the ranks before the edge pass and its gradient summed back to the
+    owners after the backward edge pass; everything else is local."""
+
+    @staticmethod
+    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=None):
+        want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
+        x = x if x.is_contiguous() else x.contiguous()
+        y, ab, aggr, cnt, maskbits, ea_t, b_all = forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, want, halo)
+        if want:
+            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, b_all)
+            ctx.graph, ctx.halo = graph, halo
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, b_all = ctx.saved_tensors
+        needs = tuple(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
+        gx, g_wn, g_we, g_wout = backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out,
+                                               ctx.graph, needs, ctx.halo, b_all)
+        return gx, None, g_wn, g_we, g_wout, None, None
 
 
 class _EgnnLayerFn(torch.autograd.Function):
@@ -205,19 +193,24 @@ def supported(x, edge_attr, *weights) -> bool:
     return False
 
 
+def _pad_width(x, w_nodes, w_out):
+    """Zero columns up to the next multiple of 8 in x and in the weight columns that meet it (differentiable
+    copies: the gradients come back in the unpadded shapes)."""
+    f = x.size(1)
+    pad = -f % 8
+    pad_cols = torch.nn.functional.pad
+    return (pad_cols(x, (0, pad)), pad_cols(w_nodes, (0, pad)),
+            torch.cat([pad_cols(w_out[:, :f], (0, pad)), w_out[:, f:]], dim=1))
+
+
 def _pad_features(x, w_nodes, w_out):
     """bfloat16 rows must be 16 bytes wide: an input width that is not a multiple of 8 (QM9: 11 atom features,
     point clouds: 3 coordinates) is padded with zero columns, in x and in the weight columns that meet it.  The
     pads are differentiable copies, so the gradients come back in the unpadded shapes."""
-    f = x.size(1)
-    pad = -f % 8
-    if pad == 0 and x.data_ptr() % 16 == 0 and x.is_contiguous():
-        return x, w_nodes, w_out
-    pad_cols = torch.nn.functional.pad
-    x = pad_cols(x, (0, pad)) if pad else x.clone(memory_format=torch.contiguous_format)
-    if pad:
-        w_nodes = pad_cols(w_nodes, (0, pad))
-        w_out = torch.cat([pad_cols(w_out[:, :f], (0, pad)), w_out[:, f:]], dim=1)
+    if x.size(1) % 8:
+        return _pad_width(x, w_nodes, w_out)
+    if x.data_ptr() % 16 or not x.is_contiguous():
+        x = x.clone(memory_format=torch.contiguous_format)
     return x, w_nodes, w_out
 
 
@@ -235,7 +228,6 @@ def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=Non
         if halo is not None:
             raise NotImplementedError("the bfloat16 layer node has no halo exchange")
         x, w_nodes, w_out = _pad_features(x, w_nodes, w_out)
-        return _LayerFnBf16.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)
     return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph, halo)
 
 

@@ -17,7 +17,7 @@ from __future__ import annotations
 import torch
 from torch.nn import Linear
 
-from . import layer_fn
+from . import compiled_ops, layer_fn
 from .graph import graph_for
 
 
@@ -31,9 +31,11 @@ class MPNNLayerCat(torch.nn.Module):
     def forward(self, x, edge_index, edge_attr):
         f = self.in_channels
         w = self.linear.weight
-        graph = graph_for(edge_index, x.size(0))
         # [Wi ; Wj] stacked row-wise gives the [N, 2H] table (target half, source half) in one GEMM.
         w_nodes = torch.cat([w[:, :f], w[:, f:2 * f]], dim=0)
+        if torch.compiler.is_compiling():      # torch.compile(model), experiments/flickr_exp.py:30: one opaque operator
+            return compiled_ops.layer(x, edge_index, edge_attr, w_nodes, w[:, 2 * f:], self.linear_out.weight)
+        graph = graph_for(edge_index, x.size(0))
         return layer_fn.layer_forward(x, edge_attr, w_nodes, w[:, 2 * f:], self.linear_out.weight, graph)
 
 
@@ -46,8 +48,11 @@ class MPNNLayerSum(torch.nn.Module):
         self.linear_out = Linear(out_channels + in_channels, out_channels, bias=False)
 
     def forward(self, x, edge_index, edge_attr):
-        graph = graph_for(edge_index, x.size(0))
         # xs = AB[:, :H] (target half), xt = AB[:, H:] (source half) of the fused projection
+        if torch.compiler.is_compiling():      # torch.compile(model), experiments/flickr_exp.py:30: one opaque operator
+            return compiled_ops.layer(x, edge_index, edge_attr, self.fused_linear.weight, self.linear_3.weight,
+                                      self.linear_out.weight)
+        graph = graph_for(edge_index, x.size(0))
         return layer_fn.layer_forward(x, edge_attr, self.fused_linear.weight, self.linear_3.weight,
                                       self.linear_out.weight, graph)
 

@@ -10,6 +10,7 @@ import torch.nn.functional as F
 from torch.nn import Linear
 
 from .layers import EGNNLayer, MPNNLayerCat, MPNNLayerSum
+from . import compiled_ops
 from .ops import global_mean_pool
 
 
@@ -54,7 +55,9 @@ class _PooledMPNN(torch.nn.Module):
     def forward(self, x, edge_index, batch, edge_attr):
         for layer in self.layers:
             x = _relu_after(layer, layer(x, edge_index, edge_attr))
-        x = global_mean_pool(x, batch)
+        # while the model is being compiled (torch.compile(model), experiments/qm9_exp.py:34) the pooling is one
+        # registered operator; eager calls take the same kernels directly
+        x = torch.ops.mpnn_amd.mean_pool(x, batch) if torch.compiler.is_compiling() else global_mean_pool(x, batch)
         return self.output_layer(x)
 
 

@@ -305,33 +305,40 @@ def egnn_aggregate(A, B, edge_attr, We, pos, w_pos, graph: MPGraph):
 # ----------------------------------------------------------------------------------------
 # segment mean (global_mean_pool)
 # ----------------------------------------------------------------------------------------
+def segment_mean_forward(x: torch.Tensor, csr: CSR) -> torch.Tensor:
+    lib = _lib.load()
+    x = x if x.stride(-1) == 1 else x.contiguous()
+    H = x.size(1)
+    out = torch.empty((csr.num_rows, H), dtype=x.dtype, device=x.device)
+    _lib.check(lib.mpnn_segment_mean_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
+                                         _lib.ptr(out), out.stride(0), csr.num_rows, H,
+                                         _lib.dtype_code(x.dtype), _lib.stream_handle(x.device)),
+               "mpnn_segment_mean_fwd")
+    return out
+
+
+def segment_mean_backward(g: torch.Tensor, csr: CSR, n: int) -> torch.Tensor:
+    lib = _lib.load()
+    g = g.contiguous()
+    H = g.size(1)
+    gx = torch.empty((n, H), dtype=g.dtype, device=g.device)
+    _lib.check(lib.mpnn_segment_mean_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
+                                         _lib.ptr(gx), gx.stride(0), csr.num_rows, H,
+                                         _lib.dtype_code(g.dtype), _lib.stream_handle(g.device)),
+               "mpnn_segment_mean_bwd")
+    return gx
+
+
 class _SegmentMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, csr: CSR):
-        lib = _lib.load()
-        x = x if x.stride(-1) == 1 else x.contiguous()
-        H = x.size(1)
-        out = torch.empty((csr.num_rows, H), dtype=x.dtype, device=x.device)
-        _lib.check(lib.mpnn_segment_mean_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
-                                             _lib.ptr(out), out.stride(0), csr.num_rows, H,
-                                             _lib.dtype_code(x.dtype), _lib.stream_handle(x.device)),
-                   "mpnn_segment_mean_fwd")
         ctx.csr = csr
         ctx.n = x.size(0)
-        return out
+        return segment_mean_forward(x, csr)
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
-        csr = ctx.csr
-        g = g.contiguous()
-        H = g.size(1)
-        gx = torch.empty((ctx.n, H), dtype=g.dtype, device=g.device)
-        _lib.check(lib.mpnn_segment_mean_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
-                                             _lib.ptr(gx), gx.stride(0), csr.num_rows, H,
-                                             _lib.dtype_code(g.dtype), _lib.stream_handle(g.device)),
-                   "mpnn_segment_mean_bwd")
-        return gx, None
+        return segment_mean_backward(g, ctx.csr, ctx.n), None
 
 
 _POOL_CACHE = {}
@@ -348,23 +355,29 @@ def register_pool(batch: torch.Tensor, num_graphs: int, rowptr: torch.Tensor, co
     _POOL_CACHE[(batch.data_ptr(), batch._version, batch.numel(), str(batch.device), None)] = (batch, csr)
 
 
+def pool_structure(batch: torch.Tensor, size: int | None) -> CSR:
+    """Segments of ``batch`` (cached for the last batch vector seen: mini-batch loops bring a new one every step)."""
+    if batch.dtype != torch.int64 or batch.dim() != 1:
+        raise ValueError("batch must be an int64 vector with one entry per node")
+    key = (batch.data_ptr(), batch._version, batch.numel(), str(batch.device), size)
+    hit = _POOL_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    if size is None:
+        size = int(batch.max().item()) + 1 if batch.numel() > 0 else 0  # host read, as in the reference
+    nodes = torch.arange(batch.numel(), dtype=torch.int64, device=batch.device)
+    csr = build_csr(batch.contiguous(), nodes, size, batch.numel())
+    _POOL_CACHE.clear()
+    _POOL_CACHE[key] = (batch, csr)
+    return csr
+
+
 @torch.compiler.disable
 def global_mean_pool(x: torch.Tensor, batch: torch.Tensor, size: int | None = None) -> torch.Tensor:
     """Per-graph mean of node rows; same contract as PyG's global_mean_pool (models/mpnn.py:54,150)."""
     _lib.require_device(x, "x")
     if batch is None:
         return x.mean(dim=0, keepdim=True)
-    if batch.dtype != torch.int64 or batch.dim() != 1 or batch.numel() != x.size(0):
+    if batch.numel() != x.size(0):
         raise ValueError("batch must be an int64 vector with one entry per node")
-    key = (batch.data_ptr(), batch._version, batch.numel(), str(batch.device), size)
-    hit = _POOL_CACHE.get(key)
-    if hit is None:
-        if size is None:
-            size = int(batch.max().item()) + 1 if batch.numel() > 0 else 0  # host read, as in the reference
-        nodes = torch.arange(batch.numel(), dtype=torch.int64, device=batch.device)
-        csr = build_csr(batch.contiguous(), nodes, size, batch.numel())
-        _POOL_CACHE.clear()  # one entry: mini-batch loops bring a new batch vector every step
-        _POOL_CACHE[key] = (batch, csr)
-    else:
-        csr = hit[1]
-    return _SegmentMean.apply(x, csr)
+    return _SegmentMean.apply(x, pool_structure(batch, size))

@@ -87,6 +87,52 @@ def test_backward_is_linear_in_upstream_gradient():
     assert g.by_dst.n_parts > 0 and g.by_src.n_split >= 0
 
 
+@pytest.mark.parametrize("mode", ["sum", "cat"])
+@pytest.mark.parametrize("kind", ["node model", "pooled model"])
+def test_torch_compile_traces_the_model_without_graph_breaks(kind, mode):
+    """The reference experiments call torch.compile(model) (experiments/flickr_exp.py:30, qm9_exp.py:34).  While a
+    model is compiled its layers and the pooling are registered operators (mpnn_amd::layer_fwd / mean_pool): the
+    whole forward is ONE captured graph (fullgraph=True would raise on a break), the outputs are the eager ones bit
+    for bit - the same kernels run in the same order - and the gradients agree to rounding."""
+    import torch._dynamo
+    from mpnn_amd import MPNN, MPNN_QM9, synth
+    dev = torch.device("cuda:0")
+    torch._dynamo.reset()
+    if kind == "node model":
+        d = synth.flickr(dev, 0, num_nodes=3000, num_edges=30000, num_features=50)
+        torch.manual_seed(0)
+        model = MPNN(50, 64, 7, num_layers=2, mode=mode).to(dev)
+        args = (d["x"], d["edge_index"], d["edge_attr"])
+        loss_of = lambda out: torch.nn.functional.cross_entropy(out[d["train_mask"]], d["y"][d["train_mask"]])
+    else:
+        d = synth.qm9(dev, 0, 64)
+        torch.manual_seed(0)
+        model = MPNN_QM9(11, 4, 64, 19, num_layers=2, mode=mode).to(dev)
+        args = (d["x"], d["edge_index"], d["batch"], d["edge_attr"])
+        loss_of = lambda out: torch.nn.functional.mse_loss(out[0], d["y"][0])     # training/train.py:22
+
+    def run(m):
+        model.zero_grad()
+        out = m(*args)
+        loss_of(out).backward()
+        return out.detach().clone(), [p.grad.clone() for p in model.parameters()]
+
+    want = run(model)
+    report = torch._dynamo.explain(model)(*args)
+    assert report.graph_break_count == 0 and report.graph_count == 1, report
+    compiled = torch.compile(model, fullgraph=True)
+    got = run(compiled)
+    assert torch.equal(got[0], want[0])
+    # the head and the loss around the operators are compiled by inductor, whose reductions (e.g. the bias gradient,
+    # a sum over all rows) add in another order than eager's: gradients agree to rounding, not bit for bit
+    for (k, _), a, b in zip(model.named_parameters(), got[1], want[1]):
+        assert_close(a, b, 1e-5, what=f"compiled grad {k}")
+    again = run(compiled)                      # second call: the compiled code, not the trace
+    assert torch.equal(again[0], want[0])
+    with torch.no_grad():                      # inference: no backward information is produced
+        assert torch.equal(compiled(*args), want[0])
+
+
 def test_torch_compile_wraps_the_model():
     """The reference experiments call torch.compile(model) (experiments/flickr_exp.py:30); the wrapped model must
     run forward and backward and agree with the eager model."""

@@ -119,8 +119,21 @@ for mode in ("sum", "cat"):
     t_lit, t_fused = timeit(literal), timeit(fused)
     cap = CapturedStep(fused)
     t_cap = timeit(cap.replay)
-    print(f"flickr full-graph model step ({mode}): reference-literal loss+Adam {t_lit:.3f} ms  fused loss+FlatAdam "
-          f"{t_fused:.3f} ms  HIP-graph replay {t_cap:.3f} ms", flush=True)
+    # the reference's own form: compiled_model = torch.compile(model) (experiments/flickr_exp.py:30)
+    m3 = torch.compile(m1)
+
+    def literal_compiled():
+        o1.zero_grad()
+        out = m3(fd.x, fd.edge_index, fd.edge_attr)
+        loss = F.cross_entropy(out[fd.train_mask], fd.y[fd.train_mask])
+        loss.backward()
+        o1.step()
+        return loss
+
+    t_comp = timeit(literal_compiled)
+    print(f"flickr full-graph model step ({mode}): reference-literal loss+Adam {t_lit:.3f} ms  the same with "
+          f"torch.compile(model) {t_comp:.3f} ms  fused loss+FlatAdam {t_fused:.3f} ms  HIP-graph replay {t_cap:.3f} ms",
+          flush=True)
 
 # ------------------------------------------------------------------------------------------------
 # fixed-size point-cloud batches: every batch is written over the same buffers and the training step is
@@ -163,3 +176,19 @@ for bs in (128, 1024):
     t = timeit(lambda: fast.train(rq.permutation(q.num_graphs)[:bs]), 60, 15)
     print(f"qm9 batch={bs}: padded batch (capacity {fast.capacity[0]} nodes / {fast.capacity[1]} edges) + HIP-graph "
           f"replay of the model step {t:.3f} ms/step", flush=True)
+
+
+# ------------------------------------------------------------------------------------------------
+# QM9 batch of 128, the reference's step literally, eager and with torch.compile(model) (experiments/qm9_exp.py:34)
+# ------------------------------------------------------------------------------------------------
+mq3 = MPNN_QM9(11, 4, 64, 19, num_layers=2, mode="sum").to(dev)
+oq3 = torch.optim.Adam(mq3.parameters(), lr=0.003)
+bq = q.collate(np.arange(128))
+for name, mdl in (("eager", mq3), ("torch.compile(model)", torch.compile(mq3))):
+    def qstep():
+        oq3.zero_grad()
+        out = mdl(bq.x, bq.edge_index, bq.batch, bq.edge_attr)
+        loss = F.mse_loss(out[0], bq.y[0])
+        loss.backward()
+        oq3.step()
+    print(f"qm9 batch=128 reference-literal step, {name}: {timeit(qstep, 60, 15):.3f} ms", flush=True)
