@@ -6,8 +6,8 @@
 A step is one full forward + backward of one MPNN layer (node GEMMs, fused gather/message/
 aggregate pass, update GEMM, and every gradient: x, all weights) on a synthetic graph whose
 tensors are already in HBM.  With N > 1 the graph is partitioned by destination range and the
-step includes the halo all-gather, the reduce-scatter of the halo gradient and the weight
-gradient all-reduce (one process per GPU).  Started without a launcher (`python bench.py --gpus N`, no
+step includes the halo exchange of the source rows, the exchange of their gradient back to the owners and the
+weight gradient all-reduce (one process per GPU); `exchange_per_layer_rank0` gives the bytes on the wire.  Started without a launcher (`python bench.py --gpus N`, no
 WORLD_SIZE in the environment) the script starts N ranks itself through torch.distributed.run, as a child
 process and before anything touches the GPU.
 
@@ -291,6 +291,12 @@ def main():
     ap.add_argument("--first-layer", action="store_true",
                     help="time the layer as the FIRST layer of a model: x is data, no gradient with respect to x "
                          "(default: a middle layer, every gradient including the input's)")
+    ap.add_argument("--halo", default="auto", choices=["auto", "all_gather", "rows"],
+                    help="partitioned runs: exchange every source row (padded all-gather) or only the rows a rank's "
+                         "edges read (all-to-all); auto picks rows when the ranks read less than 3/4 of the rows")
+    ap.add_argument("--halo-wire", default="native", choices=["native", "bf16"],
+                    help="partitioned runs: dtype of the rows on the wire (bf16 halves the bytes and leaves the "
+                         "single-GPU numerics)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
     args = ap.parse_args()
@@ -316,7 +322,7 @@ def main():
             dist.init_process_group(args.backend)
 
     from mpnn_amd import MPNNLayerCat, MPNNLayerSum, ops
-    from mpnn_amd.partition import PartitionedGraph, allreduce_gradients, partitioned_layer
+    from mpnn_amd.partition import Halo, PartitionedGraph, allreduce_gradients, partitioned_layer
 
     cfg = WORKLOADS[args.workload]
     dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
@@ -371,8 +377,20 @@ def main():
             raise SystemExit(f"rank {rank}: the ranks built different graphs or partitions ({sig.tolist()})")
         x = pg.local_rows(d["x"]).to(dtype).clone().requires_grad_(not args.first_layer)
         ea = pg.local_edges(d["edge_attr"]).to(dtype).clone()
-        n_rows_fwd, n_rows_bwd, e_local = pg.n_local, world * pg.n_pad, pg.edge_ids.numel()
-        forward = lambda: partitioned_layer(layer, x, pg, ea)
+        if args.first_layer:
+            # the layer reads the dataset's features, which every rank holds: it projects all source rows itself
+            # and nothing is exchanged but the weight gradients
+            halo, x_all = None, d["x"].to(dtype).clone()
+            exchange = {"mode": "none (first layer on replicated features)", "fwd_bytes_received": 0, "bwd_bytes_sent": 0}
+            n_rows_bwd = n_total
+        else:
+            halo = Halo(pg, mode=args.halo, wire_dtype=torch.bfloat16 if args.halo_wire == "bf16" else None)
+            x_all = None
+            exchange = halo.wire_bytes(H, s)
+            n_rows_bwd = halo.graph.num_src
+        exchange["referenced_fraction_of_rows"] = pg.referenced_fraction()
+        n_rows_fwd, e_local = pg.n_local, pg.edge_ids.numel()
+        forward = lambda: partitioned_layer(layer, x, pg, ea, halo=halo, x_all=x_all)
     keep = d if world == 1 else None      # the single-GPU run checks itself and times a model step afterwards
     del d
     torch.cuda.empty_cache()
@@ -489,7 +507,7 @@ def main():
                        "in_features": F_in, "hidden": H, "edge_features": Fe,
                        "parallelism": "single GPU" if world == 1 else (
                            (f"data parallel x{world}: one batch per rank + gradient all-reduce" if data_parallel
-                            else f"dst-range partition x{world} + halo all-gather")
+                            else f"dst-range partition x{world} + halo exchange ({exchange['mode']})")
                            + f" ({dist.get_backend()} reports {dist.get_world_size()} ranks)"),
                        "launch": "HIP graph replay" if run_step is not step else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
@@ -501,6 +519,8 @@ def main():
                 "three_pass_model_bytes": model_bytes,
                 "three_pass_model_frac_of_hbm_peak": model_bytes / mp_time / 1e9 / HBM_PEAK_GBS},
         }
+        if world > 1 and not data_parallel:
+            result["exchange_per_layer_rank0"] = exchange
         if graph_build_ms is not None:
             result["graph_build"] = {
                 "ms": graph_build_ms,

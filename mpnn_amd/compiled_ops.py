@@ -32,7 +32,7 @@ def layer_fwd(x: Tensor, edge_index: Tensor, edge_attr: Tensor, w_nodes: Tensor,
               train: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
     graph = graph_for(edge_index, x.size(0))
     x = x if x.is_contiguous() and x.data_ptr() % 16 == 0 else x.clone(memory_format=torch.contiguous_format)
-    y, ab, aggr, cnt, maskbits, _, _ = layer_fn.forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, train)
+    y, ab, aggr, cnt, maskbits, _ = layer_fn.forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, train)
     h = w_out.size(0)
     if cnt is None:
         cnt = torch.empty((0, h), dtype=torch.float32, device=x.device)

@@ -20,17 +20,15 @@ from .dense import gemm_nt, gemm_nt_bf16, gemm_tn, gemm_tn_bf16
 from .graph import MPGraph
 
 
-def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: bool, halo=None):
-    """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea_t, b_all); cnt / maskbits are
-    None when ``want`` (a backward will follow) is false or no mask layout exists, b_all is the gathered source
-    table when a partitioned layer's backward will need it again."""
+def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: bool):
+    """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea_t); cnt / maskbits are None
+    when ``want`` (a backward will follow) is false or no mask layout exists."""
     bf = x.dtype == torch.bfloat16
     x = x if x.is_contiguous() else x.contiguous()
     f = x.size(1)
     h = w_out.size(0)
     ab = gemm_nt_bf16(x, w_nodes.contiguous()) if bf else gemm_nt(x, w_nodes)
-    a = ab[:, :h]
-    b = ab[:, h:] if halo is None else halo.gather(ab[:, h:])
+    a, b = ab[:, :h], ab[:, h:]
     ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
     aggr, cnt, maskbits = ops._run_forward(a, b, ea_s, w_edge.contiguous(), graph.by_dst, graph, want)
     if bf:
@@ -39,13 +37,10 @@ def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: boo
         y = gemm_nt(x, w_out[:, :f], aggr, w_out[:, f:], relu=True)
     if want and maskbits is not None:
         graph.tpos                       # built once per graph, outside the backward
-    # the gathered source table is only read again by the recomputing backward
-    b_all = b if (want and halo is not None and maskbits is None) else None
-    return y, ab, aggr, cnt, maskbits, ea_t, b_all
+    return y, ab, aggr, cnt, maskbits, ea_t
 
 
-def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, graph: MPGraph, needs,
-                  halo=None, b_all=None):
+def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, graph: MPGraph, needs):
     """The backward sequence.  ``needs`` = (x, w_nodes, w_edge, w_out) gradients wanted; returns them in that order
     (None where not wanted)."""
     need_x, need_wn, need_we, need_wout = needs
@@ -81,41 +76,33 @@ def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_ou
     elif g_wout is not None:
         gemm_tn(gy, x, mask=y, out=g_wout, x2=aggr)
     ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt, out2=g_ab[:, :h])
-    if halo is None:
-        g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
-    else:   # gradient for every source row this rank's edges read, then summed back to the owners
-        gb_all = torch.empty((graph.num_src, h), dtype=ab.dtype, device=ab.device)
-        g_we = ops._run_backward_src(ab[:, :h], b_all, ga, ea_t, w_edge, graph.by_src, graph, gb_all, maskbits)
-        halo.scatter_sum(gb_all, g_ab[:, h:])
+    g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
     gx = gemm_nt(g, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=m) if need_x else None
     g_wn = gemm_tn(g_ab, x) if need_wn else None
     return gx, g_wn, g_we if need_we else None, g_wout
 
 
 class _LayerFn(torch.autograd.Function):
-    """The layer as one autograd node, float32 or bfloat16 storage (float32 accumulation throughout).
-
-    ``halo`` (partitioned graphs, see partition.Halo): the rows of x are this rank's destination range, the
-    source-side projection is exchanged across the ranks before the edge pass and its gradient summed back to the
-    owners after the backward edge pass; everything else is local."""
+    """The layer as one autograd node, float32 or bfloat16 storage (float32 accumulation throughout).  (The layer
+    of one rank of a partitioned graph, with its two exchanges, is partition._PartitionedLayerFn.)"""
 
     @staticmethod
-    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=None):
+    def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
         want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
         x = x if x.is_contiguous() else x.contiguous()
-        y, ab, aggr, cnt, maskbits, ea_t, b_all = forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, want, halo)
+        y, ab, aggr, cnt, maskbits, ea_t = forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, want)
         if want:
-            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, b_all)
-            ctx.graph, ctx.halo = graph, halo
+            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out)
+            ctx.graph = graph
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, b_all = ctx.saved_tensors
+        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
         needs = tuple(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
         gx, g_wn, g_we, g_wout = backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out,
-                                               ctx.graph, needs, ctx.halo, b_all)
-        return gx, None, g_wn, g_we, g_wout, None, None
+                                               ctx.graph, needs)
+        return gx, None, g_wn, g_we, g_wout, None
 
 
 class _EgnnLayerFn(torch.autograd.Function):
@@ -222,13 +209,11 @@ def _check_dtypes(x, edge_attr, *weights):
 
 
 @torch.compiler.disable
-def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, halo=None) -> torch.Tensor:
+def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph) -> torch.Tensor:
     _check_dtypes(x, edge_attr, w_nodes, w_edge, w_out)
     if x.dtype == torch.bfloat16:
-        if halo is not None:
-            raise NotImplementedError("the bfloat16 layer node has no halo exchange")
         x, w_nodes, w_out = _pad_features(x, w_nodes, w_out)
-    return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph, halo)
+    return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)
 
 
 @torch.compiler.disable

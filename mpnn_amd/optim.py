@@ -43,9 +43,11 @@ class FlatAdam:
         """Keeps the gradient tensors (they are views of the flat buffer) and clears them in one pass."""
         self.flat_grad.zero_()
 
-    def step(self) -> None:
+    def gather_stray_gradients(self) -> None:
+        """Makes ``flat_grad`` hold every gradient: one that autograd replaced instead of accumulating into is copied
+        back and the parameter re-pointed at its slice."""
         off = 0
-        for p in self.params:    # a gradient that autograd replaced instead of accumulating into is copied back
+        for p in self.params:
             k = p.numel()
             if p.grad is None:
                 self.flat_grad[off:off + k].zero_()
@@ -54,6 +56,9 @@ class FlatAdam:
                 self.flat_grad[off:off + k].copy_(p.grad.reshape(-1))
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
             off += k
+
+    def step(self) -> None:
+        self.gather_stray_gradients()
         lib = _lib.load()
         _lib.check(lib.mpnn_adam_step(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
                                       _lib.ptr(self.exp_avg_sq), self.flat.numel(), _lib.ptr(self.state), self.lr,

@@ -228,6 +228,19 @@ def dst_range_partition(rowptr: torch.Tensor, world: int):
     return bounds
 
 
+def halo_row_lists(edge_index: torch.Tensor, bounds: list, rank: int):
+    """Rows of every peer that rank ``rank`` of a destination-range partition must receive: for the edges whose
+    target lies in [bounds[rank], bounds[rank+1]), the sorted distinct source ids, grouped by the range that owns
+    them and numbered inside that range.  Returns a list (one int64 tensor per peer).  Plain Python sets."""
+    lo, hi = bounds[rank], bounds[rank + 1]
+    src, dst = edge_index[0].tolist(), edge_index[1].tolist()
+    need = sorted({s for s, d in zip(src, dst) if lo <= d < hi})
+    out = []
+    for q in range(len(bounds) - 1):
+        out.append(torch.tensor([s - bounds[q] for s in need if bounds[q] <= s < bounds[q + 1]], dtype=torch.int64))
+    return out
+
+
 # ----------------------------------------------------------------------------
 # EGNN coordinate update (no reference counterpart)
 # ----------------------------------------------------------------------------
