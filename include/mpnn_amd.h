@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 8
+#define MPNN_ABI_VERSION 9
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -92,6 +92,21 @@ int32_t mpnn_items_build(const int32_t* rowptr, int64_t num_nodes, int32_t chunk
                          int32_t max_parts, int32_t* items, int64_t items_capacity,
                          int32_t* split, int64_t split_capacity, int32_t* meta,
                          void* workspace, int64_t workspace_bytes, mpnn_stream_t stream);
+
+/* Rows of a sorted view (rowptr/col/eid from mpnn_csr_build) moved into the order in which mpnn_items_build lists
+ * them for the same `chunk`: rows longer than chunk first (row order), then by descending length, row order among
+ * equals.  Edges keep their order inside a row.  The edge kernels reach a view only through the work items'
+ * {row, first, last} records, so with the rows in item order the index list, the sorted edge attributes and the
+ * relu-mask words of consecutive items lie next to each other (one sequential stream per array).
+ *   order[j]      id of the row stored at position j (int32 [N])
+ *   rowptr_out    [N + 1], indexed by storage position
+ *   col_out/eid_out [E], must not alias col/eid
+ * Same index handling as mpnn_csr_build replaces (models/layers.py:38,110); no reference counterpart of its own. */
+int64_t mpnn_csr_item_order_workspace_bytes(int64_t num_nodes);
+int32_t mpnn_csr_item_order(const int32_t* rowptr, const int32_t* col, const int32_t* eid,
+                            int64_t num_nodes, int64_t num_edges, int32_t chunk, int32_t* order,
+                            int32_t* rowptr_out, int32_t* col_out, int32_t* eid_out, void* workspace,
+                            int64_t workspace_bytes, mpnn_stream_t stream);
 
 /* dst[r, :] = src[index[r], :] for rows of `row_bytes` bytes (row_bytes % 2 == 0).
  * Used to lay edge_attr out in CSR order once per graph (eid / eid_t from above). */

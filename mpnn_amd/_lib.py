@@ -13,7 +13,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -56,6 +56,9 @@ SIGNATURES = {
     "mpnn_items_workspace_bytes": (c_int64, [c_int64]),
     "mpnn_items_build": (c_int32, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpnn_csr_item_order_workspace_bytes": (c_int64, [c_int64]),
+    "mpnn_csr_item_order": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mpnn_gather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpnn_aggregate_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,

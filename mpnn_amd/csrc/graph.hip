@@ -21,9 +21,11 @@ char* error_buffer() {
 // ---------------------------------------------------------------------------------------
 // CSR build
 // ---------------------------------------------------------------------------------------
+// keys32[e] = key of edge e (clamped into range), payload[e] = (other of edge e, clamped) << 32 | e: the neighbour
+// id travels through the sort beside the edge id, so no random gather by edge id follows the sort.
 __global__ void k_prepare_keys(const int64_t* __restrict__ key, const int64_t* __restrict__ other,
                                int64_t E, int64_t N, int64_t M, int32_t* __restrict__ keys32,
-                               int32_t* __restrict__ status) {
+                               uint64_t* __restrict__ payload, int32_t* __restrict__ status) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   bool bad = false;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
@@ -31,31 +33,30 @@ __global__ void k_prepare_keys(const int64_t* __restrict__ key, const int64_t* _
     int64_t o = other[e];
     if (k < 0 || k >= N || o < 0 || o >= M) bad = true;
     k = k < 0 ? 0 : (k >= N ? N - 1 : k);
+    o = o < 0 ? 0 : (o >= M ? M - 1 : o);
     keys32[e] = (int32_t)k;
+    payload[e] = ((uint64_t)(uint32_t)o << 32) | (uint32_t)e;
   }
   if (bad) status[0] = 1;  // every writer stores the same value
 }
 
-// rowptr[k] = first sorted position whose key is >= k.  One thread per position p in
-// [0, E]; it owns the key values in (key[p-1], key[p]], so every rowptr entry has exactly
-// one writer.
-__global__ void k_rowptr_from_sorted(const int32_t* __restrict__ sorted, int64_t E, int64_t N,
-                                     int32_t* __restrict__ rowptr) {
+// After the sort, one thread per position p in [0, E]:
+//   col[p], eid[p] = the two halves of the payload;
+//   rowptr[k] = first sorted position whose key is >= k: the thread owns the key values in (key[p-1], key[p]], so
+//   every rowptr entry has exactly one writer.
+__global__ void k_unpack_sorted(const int32_t* __restrict__ sorted, const uint64_t* __restrict__ payload, int64_t E,
+                                int64_t N, int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                int32_t* __restrict__ eid) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p <= E; p += stride) {
     int64_t prev = p > 0 ? sorted[p - 1] : -1;
     int64_t cur = p < E ? sorted[p] : N;
     for (int64_t k = prev + 1; k <= cur; ++k) rowptr[k] = (int32_t)p;
-  }
-}
-
-__global__ void k_gather_other(const int64_t* __restrict__ other, const int32_t* __restrict__ eid,
-                               int64_t E, int64_t N, int32_t* __restrict__ col) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += stride) {
-    int64_t o = other[eid[p]];
-    o = o < 0 ? 0 : (o >= N ? N - 1 : o);
-    col[p] = (int32_t)o;
+    if (p < E) {
+      const uint64_t v = payload[p];
+      col[p] = (int32_t)(v >> 32);
+      eid[p] = (int32_t)(uint32_t)v;
+    }
   }
 }
 
@@ -68,8 +69,8 @@ static unsigned key_bits(int64_t N) {
 static hipError_t sort_temp_bytes(int64_t E, int64_t N, size_t& bytes) {
   bytes = 0;
   int32_t* kn = nullptr;
-  return rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0),
-                                   kn, (size_t)E, 0u, key_bits(N), (hipStream_t)0);
+  uint64_t* vn = nullptr;
+  return rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, vn, vn, (size_t)E, 0u, key_bits(N), (hipStream_t)0);
 }
 
 static int grid_for(int64_t n) {
@@ -190,6 +191,69 @@ static hipError_t scan_temp_bytes(int64_t n, size_t& bytes) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Rows of a sorted view moved into work-item order
+// ---------------------------------------------------------------------------------------
+// key[n] as in k_item_counts (split rows 0, then 1 + chunk - deg); deg[n].
+__global__ void k_row_order_keys(const int32_t* __restrict__ rowptr, int64_t N, int chunk, int32_t* __restrict__ key) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+    const int deg = rowptr[n + 1] - rowptr[n];
+    key[n] = deg > chunk ? 0 : 1 + chunk - deg;
+  }
+}
+
+// deg_o[j] = degree of the row stored at position j (entry N = 0: the terminator of the exclusive scan)
+__global__ void k_degrees_in_order(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ order, int64_t N,
+                                   int32_t* __restrict__ deg_o) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j <= N; j += stride)
+    deg_o[j] = j < N ? rowptr[order[j] + 1] - rowptr[order[j]] : 0;
+}
+
+constexpr int kPermTile = 2048;   // output positions per block
+
+// Output position p belongs to the stored row j with newptr[j] <= p < newptr[j+1]; its entry comes from
+// position rowptr[order[j]] + (p - newptr[j]) of the old arrays.  A block finds the rows its tile of positions
+// touches once, then every thread searches inside that small window: balanced whatever the degrees are.
+__global__ void __launch_bounds__(kBlock) k_permute_segments(const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ order,
+                                                             const int32_t* __restrict__ newptr, int64_t N, int64_t E,
+                                                             const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ eid,
+                                                             int32_t* __restrict__ col_out,
+                                                             int32_t* __restrict__ eid_out) {
+  __shared__ int64_t win[2];
+  const int64_t tiles = (E + kPermTile - 1) / kPermTile;
+  for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const int64_t p0 = t * kPermTile;
+    const int64_t p1 = p0 + kPermTile < E ? p0 + kPermTile : E;
+    if (threadIdx.x < 2) {
+      // last row j with newptr[j] <= q, for q = p0 (thread 0) and q = p1 - 1 (thread 1)
+      const int64_t q = threadIdx.x == 0 ? p0 : p1 - 1;
+      int64_t lo = 0, hi = N;      // invariant: newptr[lo] <= q < newptr[hi]  (newptr[N] = E > q)
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (newptr[mid] <= q) lo = mid; else hi = mid;
+      }
+      win[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    const int64_t j0 = win[0], j1 = win[1];
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += kBlock) {
+      int64_t lo = j0, hi = j1 + 1;
+      while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (newptr[mid] <= p) lo = mid; else hi = mid;
+      }
+      const int64_t src = (int64_t)rowptr[order[lo]] + (p - newptr[lo]);
+      col_out[p] = col[src];
+      eid_out[p] = eid[src];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Row gather
 // ---------------------------------------------------------------------------------------
 template <typename W>
@@ -217,8 +281,8 @@ int64_t mpnn_csr_workspace_bytes(int64_t N, int64_t E) {
   if (N < 0 || E < 0 || N >= INT32_MAX || E >= INT32_MAX) return -1;
   size_t temp = 0;
   if (sort_temp_bytes(E, N, temp) != hipSuccess) return -1;
-  // keys in, keys out, rocPRIM temporary storage (each rounded up to 256 B)
-  return 2 * align_up((E + 1) * 4, 256) + align_up((int64_t)temp + 256, 256);
+  // keys in / out, payload in / out, rocPRIM temporary storage (each rounded up to 256 B)
+  return 2 * align_up((E + 1) * 4, 256) + 2 * align_up((E + 1) * 8, 256) + align_up((int64_t)temp + 256, 256);
 }
 
 int32_t mpnn_csr_build(const int64_t* key, const int64_t* other, int64_t E, int64_t N, int64_t M, int32_t* rowptr,
@@ -239,23 +303,22 @@ int32_t mpnn_csr_build(const int64_t* key, const int64_t* other, int64_t E, int6
   Arena arena(workspace, workspace_bytes);
   int32_t* keys_in = arena.take<int32_t>(E + 1);
   int32_t* keys_out = arena.take<int32_t>(E + 1);
+  uint64_t* pay_in = arena.take<uint64_t>(E + 1);
+  uint64_t* pay_out = arena.take<uint64_t>(E + 1);
   size_t temp = 0;
   MPNN_HIP_CHECK(sort_temp_bytes(E, N, temp));
   char* temp_ptr = arena.take<char>((int64_t)temp + 256);
-  if (!keys_in || !keys_out || !temp_ptr)
+  if (!keys_in || !keys_out || !pay_in || !pay_out || !temp_ptr)
     return fail(MPNN_E_WORKSPACE, "mpnn_csr_build: workspace of %lld bytes is too small (need %lld)",
                 (long long)workspace_bytes, (long long)mpnn_csr_workspace_bytes(N, E));
 
-  k_prepare_keys<<<grid_for(E), kBlock, 0, stream>>>(key, other, E, N, M, keys_in, status);
+  k_prepare_keys<<<grid_for(E), kBlock, 0, stream>>>(key, other, E, N, M, keys_in, pay_in, status);
   MPNN_LAUNCH_CHECK("k_prepare_keys");
-  // Radix sort is stable, and the values are the original edge ids, so equal keys stay in edge order.
-  MPNN_HIP_CHECK(rocprim::radix_sort_pairs(temp_ptr, temp, keys_in, keys_out,
-                                           rocprim::counting_iterator<int32_t>(0), eid, (size_t)E, 0u,
+  // Radix sort is stable, and the payload's low half is the original edge id, so equal keys stay in edge order.
+  MPNN_HIP_CHECK(rocprim::radix_sort_pairs(temp_ptr, temp, keys_in, keys_out, pay_in, pay_out, (size_t)E, 0u,
                                            key_bits(N), stream));
-  k_rowptr_from_sorted<<<grid_for(E + 1), kBlock, 0, stream>>>(keys_out, E, N, rowptr);
-  MPNN_LAUNCH_CHECK("k_rowptr_from_sorted");
-  k_gather_other<<<grid_for(E), kBlock, 0, stream>>>(other, eid, E, M, col);
-  MPNN_LAUNCH_CHECK("k_gather_other");
+  k_unpack_sorted<<<grid_for(E + 1), kBlock, 0, stream>>>(keys_out, pay_out, E, N, rowptr, col, eid);
+  MPNN_LAUNCH_CHECK("k_unpack_sorted");
   return MPNN_OK;
 }
 
@@ -324,6 +387,54 @@ int32_t mpnn_items_build(const int32_t* rowptr, int64_t N, int32_t chunk, int32_
                                                            reinterpret_cast<const int4*>(split), split_capacity,
                                                            reinterpret_cast<int4*>(items), items_capacity, meta);
     MPNN_LAUNCH_CHECK("k_item_fill_pieces");
+  }
+  return MPNN_OK;
+}
+
+int64_t mpnn_csr_item_order_workspace_bytes(int64_t N) {
+  if (N < 0 || N >= INT32_MAX) return -1;
+  const int64_t temp = items_temp_bytes(N);
+  if (temp < 0) return -1;
+  return 3 * align_up((N + 1) * 4, 256) + align_up(temp + 256, 256);
+}
+
+int32_t mpnn_csr_item_order(const int32_t* rowptr, const int32_t* col, const int32_t* eid, int64_t N, int64_t E,
+                            int32_t chunk, int32_t* order, int32_t* rowptr_out, int32_t* col_out, int32_t* eid_out,
+                            void* workspace, int64_t workspace_bytes, mpnn_stream_t stream) {
+  if (N < 0 || N >= INT32_MAX || E < 0 || E >= INT32_MAX || chunk < 1)
+    return fail(MPNN_E_INVALID, "mpnn_csr_item_order: N=%lld E=%lld chunk=%d", (long long)N, (long long)E, chunk);
+  if (!rowptr || !rowptr_out || !workspace || (N > 0 && !order) || (E > 0 && (!col || !eid || !col_out || !eid_out)))
+    return fail(MPNN_E_INVALID, "mpnn_csr_item_order: null pointer argument");
+  if (col == col_out || eid == eid_out) return fail(MPNN_E_INVALID, "mpnn_csr_item_order: outputs must not alias inputs");
+  Arena arena(workspace, workspace_bytes);
+  int32_t* key = arena.take<int32_t>(N + 1);
+  int32_t* key_sorted = arena.take<int32_t>(N + 1);
+  int32_t* deg_o = arena.take<int32_t>(N + 1);
+  const int64_t temp_need = items_temp_bytes(N);
+  if (temp_need < 0) return fail(MPNN_E_HIP, "mpnn_csr_item_order: rocPRIM size query failed");
+  char* temp_ptr = arena.take<char>(temp_need + 256);
+  if (!key || !key_sorted || !deg_o || !temp_ptr)
+    return fail(MPNN_E_WORKSPACE, "mpnn_csr_item_order: workspace of %lld bytes is too small (need %lld)",
+                (long long)workspace_bytes, (long long)mpnn_csr_item_order_workspace_bytes(N));
+  if (N == 0) {
+    MPNN_HIP_CHECK(hipMemsetAsync(rowptr_out, 0, sizeof(int32_t), stream));
+    return MPNN_OK;
+  }
+  k_row_order_keys<<<grid_for(N), kBlock, 0, stream>>>(rowptr, N, chunk, key);
+  MPNN_LAUNCH_CHECK("k_row_order_keys");
+  size_t t = (size_t)temp_need;
+  MPNN_HIP_CHECK(rocprim::radix_sort_pairs(temp_ptr, t, key, key_sorted, rocprim::counting_iterator<int32_t>(0), order,
+                                           (size_t)N, 0u, order_bits(chunk), stream));
+  k_degrees_in_order<<<grid_for(N + 1), kBlock, 0, stream>>>(rowptr, order, N, deg_o);
+  MPNN_LAUNCH_CHECK("k_degrees_in_order");
+  t = (size_t)temp_need;
+  MPNN_HIP_CHECK(rocprim::exclusive_scan(temp_ptr, t, deg_o, rowptr_out, 0, (size_t)(N + 1), rocprim::plus<int32_t>(),
+                                         stream));
+  if (E > 0) {
+    int64_t blocks = (E + kPermTile - 1) / kPermTile;
+    if (blocks > 8 * kMaxBlocks) blocks = 8 * kMaxBlocks;
+    k_permute_segments<<<(int)blocks, kBlock, 0, stream>>>(rowptr, order, rowptr_out, N, E, col, eid, col_out, eid_out);
+    MPNN_LAUNCH_CHECK("k_permute_segments");
   }
   return MPNN_OK;
 }

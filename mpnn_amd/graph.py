@@ -46,7 +46,7 @@ class CSR:
         if order is None:
             return deg
         out = torch.empty_like(deg)
-        out[order] = deg          # rowptr is indexed by storage position; order[j] = row stored at position j
+        out[order.long()] = deg          # rowptr is indexed by storage position; order[j] = row stored at position j
         return out
 
 
@@ -101,19 +101,20 @@ def _rows_into_item_order(csr: CSR, status: torch.Tensor, chunk: int) -> None:
     first in row order, then descending degree, row order among equals.  Edges keep their order inside a row."""
     if int(status[0]) != 0:   # the arrays are not trustworthy: report it before indexing with them
         raise IndexError(f"edge_index holds node ids outside [0, {csr.num_rows}) x [0, {csr.num_cols})")
+    lib = _lib.load()
     n, e = csr.num_rows, csr.num_edges
-    deg = csr.rowptr[1:] - csr.rowptr[:-1]
-    sort_key = torch.where(deg > chunk, torch.zeros_like(deg), 1 + chunk - deg)
-    order = torch.argsort(sort_key, stable=True)
-    deg_o = deg[order].long()
-    newptr = torch.zeros(n + 1, dtype=torch.int64, device=deg.device)
-    torch.cumsum(deg_o, 0, out=newptr[1:])
-    shift = csr.rowptr[:-1][order].long() - newptr[:-1]          # old minus new position, per stored row
-    perm = torch.repeat_interleave(shift, deg_o, output_size=e)
-    perm += torch.arange(e, dtype=torch.int64, device=perm.device)
-    csr.col, csr.eid = csr.col[perm], csr.eid[perm]
-    csr.rowptr = newptr.to(torch.int32)
-    csr.order = order
+    dev = csr.rowptr.device
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col, eid = torch.empty_like(csr.col), torch.empty_like(csr.eid)
+    ws_bytes = lib.mpnn_csr_item_order_workspace_bytes(n)
+    if ws_bytes < 0:
+        raise _lib.MpnnError(f"mpnn_csr_item_order_workspace_bytes({n}) failed")
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.check(lib.mpnn_csr_item_order(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), _lib.ptr(csr.eid), n, e, chunk,
+                                       _lib.ptr(order), _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(eid), _lib.ptr(ws),
+                                       ws.numel(), _lib.stream_handle(dev)), "mpnn_csr_item_order")
+    csr.rowptr, csr.col, csr.eid, csr.order = rowptr, col, eid, order
 
 
 def _finish(csrs, pending) -> None:

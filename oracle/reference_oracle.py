@@ -210,6 +210,22 @@ def work_items(rowptr: torch.Tensor, chunk: int, max_parts: int):
     return items, split, pslot
 
 
+def rows_in_item_order(rowptr: torch.Tensor, col: torch.Tensor, eid: torch.Tensor, chunk: int):
+    """A sorted view with its ROWS stored in the order work_items lists them for ``chunk`` (rows longer than chunk
+    first in row order, then descending length, row order among equals); edges keep their order inside a row.
+    Returns (order [N] = row stored at each position, rowptr indexed by position, col, eid), int32.  Plain loops."""
+    rp = rowptr.to(torch.int64).tolist()
+    n = len(rp) - 1
+    order = sorted(range(n), key=lambda r: 0 if rp[r + 1] - rp[r] > chunk else 1 + chunk - (rp[r + 1] - rp[r]))
+    newptr, pos = [0], []
+    for r in order:
+        pos.extend(range(rp[r], rp[r + 1]))
+        newptr.append(newptr[-1] + rp[r + 1] - rp[r])
+    pos = torch.tensor(pos, dtype=torch.int64)
+    return (torch.tensor(order, dtype=torch.int32), torch.tensor(newptr, dtype=torch.int32),
+            col[pos].to(torch.int32), eid[pos].to(torch.int32))
+
+
 def dst_range_partition(rowptr: torch.Tensor, world: int):
     """Contiguous destination ranges balanced by in-edge count.
 

@@ -153,31 +153,51 @@ def test_default_chunk_rule():
         assert default_chunk(e) == want, (e, default_chunk(e), want)
 
 
-def test_rows_in_work_item_order_host_logic():
-    """graph._rows_into_item_order (host-side tensor code, runs on any device) moves whole rows of a sorted view
-    into the order in which the oracle's work_items lists them and keeps every row's edges as they were."""
-    from mpnn_amd.graph import CSR, _rows_into_item_order
+def test_rows_in_item_order_oracle_lists_rows_as_the_work_items_do():
+    """The oracle's item-order view against its own work_items: rows appear in the order of their first item, every
+    row keeps its edges, and the work items of the moved view are one ascending run over the edge arrays."""
     gen = torch.Generator().manual_seed(4)
     n, e, chunk = 300, 9000, 16
     dst = (torch.rand(e, generator=gen) ** 4 * n).long().clamp_(max=n - 1)     # skewed: long rows that get split
     ei = torch.stack([torch.randint(0, n, (e,), generator=gen), dst])
     ref = O.csr_build(ei, n)
-    csr = CSR()
-    csr.num_rows, csr.num_cols, csr.num_edges, csr.order = n, n, e, None
-    csr.rowptr, csr.col, csr.eid = ref["rowptr"].clone(), ref["col"].clone(), ref["eid"].clone()
-    _rows_into_item_order(csr, torch.zeros(4, dtype=torch.int32), chunk)
+    order, rowptr, col, eid = O.rows_in_item_order(ref["rowptr"], ref["col"], ref["eid"], chunk)
     items, split, _ = O.work_items(ref["rowptr"], chunk, 256)
-    rows_in_item_order = list(dict.fromkeys(items[:, 0].tolist()))            # first appearance of every row
-    assert csr.order.tolist() == rows_in_item_order and split.numel() > 0
-    assert csr.rowptr.dtype == torch.int32 and int(csr.rowptr[0]) == 0 and int(csr.rowptr[-1]) == e
+    assert order.tolist() == list(dict.fromkeys(items[:, 0].tolist())) and split.numel() > 0
+    assert int(rowptr[0]) == 0 and int(rowptr[-1]) == e
     for j in (0, 1, 7, n // 2, n - 1):
-        row = int(csr.order[j])
-        got = slice(int(csr.rowptr[j]), int(csr.rowptr[j + 1]))
+        row = int(order[j])
+        got = slice(int(rowptr[j]), int(rowptr[j + 1]))
         want = slice(int(ref["rowptr"][row]), int(ref["rowptr"][row + 1]))
-        assert torch.equal(csr.col[got], ref["col"][want]) and torch.equal(csr.eid[got], ref["eid"][want])
-    assert torch.equal(csr.degree(), ref["rowptr"][1:] - ref["rowptr"][:-1])
-    # work items of the moved view are one ascending run over the edge arrays
-    moved, _, _ = O.work_items(csr.rowptr, chunk, 256)
+        assert torch.equal(col[got], ref["col"][want]) and torch.equal(eid[got], ref["eid"][want])
+    moved, _, _ = O.work_items(rowptr, chunk, 256)
     assert torch.equal(moved[1:, 1], moved[:-1, 2]) and int(moved[0, 1]) == 0 and int(moved[-1, 2]) == e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,e,chunk,power", [(300, 9000, 16, 4), (5000, 200_000, 64, 6), (1, 50, 8, 1), (777, 0, 64, 1),
+                                             (40_000, 3_000_000, 256, 8)])
+def test_rows_in_item_order_on_the_device_are_bit_exact(n, e, chunk, power):
+    """mpnn_csr_item_order against the oracle: order, row pointers, neighbour and edge-id lists, bit for bit."""
+    from mpnn_amd.graph import MPGraph
+    gen = torch.Generator().manual_seed(n + chunk)
+    dst = (torch.rand(e, generator=gen) ** power * n).long().clamp_(max=n - 1)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), dst])
+    ref = O.csr_build(ei, n)
+    g = MPGraph(ei.cuda(), n, chunk=chunk, row_order="items")
+    for view, names in ((g.by_dst, ("rowptr", "col", "eid")), (g.by_src, ("rowptr_t", "col_t", "eid_t"))):
+        if e == 0:
+            assert view.order is None and int(view.rowptr.abs().sum()) == 0
+            continue
+        order, rowptr, col, eid = O.rows_in_item_order(*(ref[k] for k in names), chunk)
+        assert torch.equal(view.order.cpu(), order)
+        assert torch.equal(view.rowptr.cpu(), rowptr)
+        assert torch.equal(view.col.cpu(), col) and torch.equal(view.eid.cpu(), eid)
+        assert torch.equal(view.degree().cpu(), (ref[names[0]][1:] - ref[names[0]][:-1]))
     with pytest.raises(IndexError):
-        _rows_into_item_order(csr, torch.ones(4, dtype=torch.int32), chunk)
+        bad = ei.clone().cuda()
+        if e:
+            bad[1, 0] = n
+            MPGraph(bad, n, chunk=chunk, row_order="items")
+        else:
+            raise IndexError
