@@ -215,6 +215,47 @@ def verify_layer(layer, mode, x, ei, ea, n_total):
             "worst": rep["worst"]}
 
 
+def verify_egnn_layer(layer, x, pos, ei, ea, dtype):
+    """One more forward + backward of the EGNN layer against the float64 CPU oracle on the WHOLE batch (the batched
+    workloads are small enough): outputs, coordinates and every gradient.  No reference code exists for this layer
+    (parity unpinned): the oracle is the formula of oracle/reference_oracle.py::egnn_full_layer."""
+    from oracle import reference_oracle as O
+    from oracle import sampled as S
+    dev = x.device
+    H = layer.out_channels
+    gen = torch.Generator(device=dev).manual_seed(9)
+    r = torch.randn(x.size(0), H, generator=gen, device=dev)
+    rp = torch.randn(x.size(0), 3, generator=gen, device=dev)
+    params = list(layer.parameters())
+    for p in params:
+        p.grad = None
+    xg = x.detach().to(dtype).requires_grad_(True)
+    pg = pos.detach().float().requires_grad_(True)
+    y, pos_out = layer(xg, pg, ei, ea.to(dtype))
+    ((y.float() * r).sum() + (pos_out * rp).sum()).backward()
+    ws = [p.detach().double().cpu().requires_grad_(True) for p in params]   # fused_linear, linear_3, linear_out, coord_linear
+    xc, pc = xg.detach().double().cpu().requires_grad_(True), pg.detach().double().cpu().requires_grad_(True)
+    want_y, want_pos = O.egnn_full_layer(xc, pc, ei.cpu(), ea.to(dtype).double().cpu(), ws[0], ws[1], ws[2], ws[3])
+    ((want_y * r.double().cpu()).sum() + (want_pos * rp.double().cpu()).sum()).backward()
+    bf = dtype == torch.bfloat16
+    rtol = 2e-2 if bf else 1e-5
+    # gradients with the floor the GPU tests use (tests/test_gpu_egnn.py): 4 * rtol * max|want|
+    pairs = [("y", y, want_y), ("pos'", pos_out, want_pos), ("grad x", xg.grad, xc.grad, 4.0),
+             ("grad pos", pg.grad, pc.grad, 4.0)]
+    pairs += [(f"grad {k}", p.grad, w.grad, 4.0) for (k, _), p, w in zip(layer.named_parameters(), params, ws)]
+    rep = S.error_report(pairs, rtol, kink_frac=2e-3 if bf else 1e-5)
+    for p in params:
+        p.grad = None
+    return {"ok": rep["ok"], "rows": int(x.size(0)), "edges": int(ei.size(1)), "entries": rep["entries"],
+            "max_rel_err": rep["max_rel_err"], "outside_tolerance": rep["outside"],
+            "tolerance": f"|got-want| <= {rtol}*max|want| (4x for gradients) + {rtol}*|want| against the float64 CPU oracle "
+                         "(whole batch); "
+                         f"at most {'2e-3' if bf else '1e-5'} of a tensor's entries outside (relu decisions that "
+                         "differ in the storage precision)",
+            "what": "y, pos', grad x, grad pos, grad of every weight; dense upstream gradients; parity unpinned "
+                    "(no EGNN in the reference)", "worst": rep["worst"]}
+
+
 def model_step_time(mode, d, hidden, dev, steps=5, warmup=2):
     """Whole training step of the reference's loop (training/train.py:43-49) on the workload's graph: 2 layers + head
     (models/mpnn.py:86-101), cross-entropy over the masked rows, backward, Adam.  Returns seconds per step."""
@@ -540,6 +581,12 @@ def main():
                 # gradient entries differ by whole terms: the elementwise sampled check is a float32 check
                 # (tests/test_gpu_parity.py holds the bfloat16 layer tests)
                 result["verified"] = None
+        if world == 1 and keep is not None and args.layer == "egnn" and not args.no_verify and e_total <= 4_000_000:
+            note("checking the EGNN layer against the CPU oracle")
+            kpos = keep["pos"].float() if "pos" in keep else pos.detach()
+            result["verified"] = verify_egnn_layer(layer, keep["x"], kpos, keep["edge_index"], keep["edge_attr"], dtype)
+            if not result["verified"]["ok"]:
+                failed = f"verification against the CPU oracle failed: {result['verified']['worst']}"
         if world == 1 and keep is not None and args.layer == "mpnn" and args.dtype == "f32" and not args.no_model_step:
             note("timing the whole-model training step")
             del x, r

@@ -120,7 +120,8 @@ def _aggregate_two_tables(a, b, edge_attr, w_edge, edge_index):
 
 
 def error_report(pairs, rtol: float, kink_frac: float = 1e-5) -> dict:
-    """Compares (name, got, want) triples under |got - want| <= rtol * max|want| + rtol * |want|.
+    """Compares (name, got, want[, floor]) tuples under |got - want| <= floor * rtol * max|want| + rtol * |want|
+    (floor 1 unless given; the GPU tests use 4 for gradients).
 
     kink_frac: share of the entries of one tensor that may lie outside (two correct evaluations of a relu network
     can put a pre-activation that is zero to float32 rounding on different sides; a gradient then differs by one
@@ -128,7 +129,8 @@ def error_report(pairs, rtol: float, kink_frac: float = 1e-5) -> dict:
     entries inside the bound), "entries", "outside" (entries beyond the bound, at most kink_frac per tensor),
     "worst"}."""
     worst, max_rel, entries, outside, ok = "", 0.0, 0, 0, True
-    for name, got, want in pairs:
+    for name, got, want, *rest in pairs:
+        floor = rest[0] if rest else 1.0      # optional 4th entry: the absolute floor in units of rtol * max|want|
         got, want = got.detach().double().cpu(), want.detach().double().cpu()
         if got.shape != want.shape:
             return {"ok": False, "max_rel_err": float("inf"), "entries": entries, "outside": outside,
@@ -137,7 +139,7 @@ def error_report(pairs, rtol: float, kink_frac: float = 1e-5) -> dict:
             continue
         scale = max(float(want.abs().max()), 1e-30)
         err = (got - want).abs()
-        out = err > rtol * scale + rtol * want.abs()
+        out = err > rtol * floor * scale + rtol * want.abs()
         bad = int(out.sum())
         rel = float(err[~out].max()) / scale if bad < want.numel() else float("inf")   # over the entries inside
         entries += want.numel()
