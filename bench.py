@@ -70,7 +70,7 @@ def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0):
     """Compulsory bytes of one launch of this build's two edge kernels.
 
     aggregate_fwd       per edge: col, B[src] row, edge_attr (+ relu mask words written)
-                        per row:  item record, A row, out row, cnt row (float)
+                        per row:  item record, A row, out row, cnt row (one byte per column)
     aggregate_bwd_src   recomputing form, per edge: col_t, A[dst] row, G[dst] row, edge_attr
                         mask-bit form,    per edge: col_t, tpos, mask words, G[dst] row, edge_attr
                         per row:  item record, (B row,) gB row
@@ -82,7 +82,7 @@ def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0):
     if kind == "egnn_bwd_src":     # per edge: col_t, A[dst] and G[dst] rows, edge_attr, pos[dst], g pos[dst]
         return e * (4 + 2 * h * s + fe * s + 24) + n_rows * (16 + 2 * h * s + 24)
     if kind == "aggregate_fwd":
-        return e * (4 + h * s + fe * s + 4 * mask_words) + n_rows * (16 + 2 * h * s + 4 * h)
+        return e * (4 + h * s + fe * s + 4 * mask_words) + n_rows * (16 + 2 * h * s + h)
     if kind == "aggregate_bwd_src":
         if mask_words:
             return e * (8 + 4 * mask_words + h * s + fe * s) + n_rows * (16 + h * s)

@@ -30,7 +30,7 @@ extern "C" {
 
 typedef struct ihipStream_t* mpnn_stream_t; /* == hipStream_t */
 
-enum { MPNN_F32 = 0, MPNN_BF16 = 1 };
+enum { MPNN_F32 = 0, MPNN_BF16 = 1, MPNN_U8 = 2 /* only as the kind of a GEMM epilogue multiplier */ };
 
 enum {
   MPNN_OK = 0,
@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 9
+#define MPNN_ABI_VERSION 10
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -210,8 +210,15 @@ int32_t mpnn_collate(const mpnn_collate_desc* desc, mpnn_stream_t stream);
  * We        [H, Fe] row-major (the Linear weight layout), same dtype as A
  * items/split/n_*  from mpnn_items_build for this CSR
  * out       [N, H] leading dimension ldo
- * cnt       optional float [N, H]: number of edges of row n whose message is > 0 in
- *           column h (needed by the backward: d out / d A = grad * cnt); may be NULL
+ * cnt       optional uint8 [N, H] (row stride H): number of edges of row n whose message is > 0 in
+ *           column h, saturated at 255 (needed by the backward: d out / d A = grad * cnt); may be NULL.
+ *           A byte per count quarters the bytes this pass writes and the backward reads; exact for every
+ *           row of at most 255 edges.  The rows that can hold more keep exact float counts in
+ * cnt_big   float [n_split + n_big, H]: row s < n_split = the row of split record s; row n_split + j = the
+ *           row of item n_parts + j, j < n_big, where n_big = the number of UNSPLIT rows with more than 255
+ *           edges (they are the first unsplit items: unsplit items are listed by descending length).
+ *           mpnn_count_fixup rewrites grad * cnt for exactly these rows.  The byte counts of these rows are
+ *           unspecified.  May be NULL when cnt is NULL or n_split + n_big == 0.
  * part_out, part_cnt  float [n_parts, H] scratch for split rows (part_cnt may be NULL
  *           iff cnt is NULL); may be NULL when n_parts == 0
  * maskbits  optional uint32 [E, mpnn_mask_words(H, dtype)], 16-byte aligned: per CSR position the
@@ -226,9 +233,16 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
                            const void* ea_sorted, int32_t Fe, const void* We,
                            const int32_t* col, const int32_t* items, int64_t n_items,
                            const int32_t* split, int64_t n_split, int64_t n_parts,
-                           void* out, int64_t ldo, float* cnt, float* part_out,
-                           float* part_cnt, uint32_t* maskbits, int64_t num_nodes, int32_t H,
-                           int32_t dtype, mpnn_stream_t stream);
+                           void* out, int64_t ldo, uint8_t* cnt, float* cnt_big, int64_t n_big,
+                           float* part_out, float* part_cnt, uint32_t* maskbits, int64_t num_nodes,
+                           int32_t H, int32_t dtype, mpnn_stream_t stream);
+
+/* gA[row, :] = G[row, :] * cnt_big[slot, :] for the rows listed by cnt_big's slots (see mpnn_aggregate_fwd):
+ * run after the GEMM whose epilogue wrote gA = G * cnt from the byte counts, it makes d out / d A exact for the
+ * rows whose counts can exceed a byte.  Part of the autograd backward of the aggregation (training/train.py:23,48,76). */
+int32_t mpnn_count_fixup(const void* G, int64_t ldG, const float* cnt_big, const int32_t* items,
+                         const int32_t* split, int64_t n_split, int64_t n_parts, int64_t n_big,
+                         void* gA, int64_t ldgA, int32_t H, int32_t dtype, mpnn_stream_t stream);
 
 /* mpnn_aggregate_fwd for callers that cannot allocate device memory at all (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc): the partial-sum slabs of split rows (part_out, part_cnt)
@@ -246,8 +260,9 @@ int32_t mpnn_aggregate_fwd_noalloc(const void* A, int64_t ldA, const void* B, in
                                    const void* ea_sorted, int32_t Fe, const void* We,
                                    const int32_t* col, const int32_t* items, int64_t n_items,
                                    const int32_t* split, int64_t n_split, int64_t n_parts,
-                                   void* out, int64_t ldo, float* cnt, uint32_t* maskbits,
-                                   int64_t num_nodes, int32_t H, int32_t dtype, mpnn_stream_t stream);
+                                   void* out, int64_t ldo, uint8_t* cnt, float* cnt_big, int64_t n_big,
+                                   uint32_t* maskbits, int64_t num_nodes, int32_t H, int32_t dtype,
+                                   mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Backward of the aggregation with respect to B (the per-source table) and We.
@@ -350,7 +365,8 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
  *   XI * (maskI > 0) -- the relu backward fused into the operand load.  With a pre-transposed weight the
  *   same entry point computes input gradients (dX = G W  ==  G (W^T)^T).
  *   Y2 (optional, with emul [N,M]): second output Y2 = Y * emul written by the same epilogue
- *   (d aggr and d A = d aggr * cnt leave one GEMM together).
+ *   (d aggr and d A = d aggr * cnt leave one GEMM together).  emul_kind: MPNN_F32 (float) or MPNN_U8 (one
+ *   byte per entry, the counts of mpnn_aggregate_fwd); ldemul in elements of that kind.
  *   Arithmetic: by default every float32 operand is split into three bfloat16 pieces and the products run on
  *   the bfloat16 matrix cores with float32 accumulation (six piece products per product; error against a
  *   float64 product no larger than the float32 matrix cores'); MPNN_GEMM=f32 in the environment selects the
@@ -369,8 +385,8 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
 int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int64_t ldm1,
                          const float* W1, int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2,
                          const float* mask2, int64_t ldm2, const float* W2, int64_t ldw2, int32_t K2,
-                         float* Y, int64_t ldy, const float* emul, int64_t ldemul, float* Y2,
-                         int64_t ldy2, int64_t N, int32_t M, int32_t relu, void* scratch,
+                         float* Y, int64_t ldy, const void* emul, int32_t emul_kind, int64_t ldemul,
+                         float* Y2, int64_t ldy2, int64_t N, int32_t M, int32_t relu, void* scratch,
                          mpnn_stream_t stream);
 int64_t mpnn_gemm_nt_scratch_bytes(int32_t M, int32_t K1, int32_t K2);
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K);
@@ -380,13 +396,13 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
                          int32_t K, int32_t K2, mpnn_stream_t stream);
 
 /* bfloat16 form of mpnn_gemm_nt_f32 for bfloat16 models (bf16 storage, float32 accumulation, no operand mask):
- *   Y[N,M] = act( X1 W1^T + X2 W2^T ),  optionally  Y2 = Y * emul  with emul float32 [N,M].
+ *   Y[N,M] = act( X1 W1^T + X2 W2^T ),  optionally  Y2 = Y * emul  with emul [N,M] float32 or bytes (emul_kind).
  * M, K1, K2 multiples of 8; X, W, emul 16-byte aligned, Y and Y2 8-byte aligned, with row strides that keep
  * every row so. */
 int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W1, int64_t ldw1, int32_t K1,
                           const void* X2, int64_t ldx2, const void* W2, int64_t ldw2, int32_t K2, void* Y,
-                          int64_t ldy, const float* emul, int64_t ldemul, void* Y2, int64_t ldy2, int64_t N,
-                          int32_t M, int32_t relu, mpnn_stream_t stream);
+                          int64_t ldy, const void* emul, int32_t emul_kind, int64_t ldemul, void* Y2,
+                          int64_t ldy2, int64_t N, int32_t M, int32_t relu, mpnn_stream_t stream);
 /* bfloat16 form of mpnn_gemm_tn_f32 (the weight gradients of the same Linear calls): G, mask, X, Gout and dW
  * bfloat16, float32 accumulation over the rows in a fixed order, one rounding to bfloat16 at the end.
  * X2 / K2 as in mpnn_gemm_tn_f32.  `scratch`: at least mpnn_gemm_tn_bf16_scratch_floats(N, M, K + K2) floats.  M and K multiples of 8; G, mask, X, Gout

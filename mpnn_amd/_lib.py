@@ -13,7 +13,8 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 
 MPNN_F32 = 0
 MPNN_BF16 = 1
-ABI_VERSION = 9
+MPNN_U8 = 2
+ABI_VERSION = 10
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -62,12 +63,14 @@ SIGNATURES = {
     "mpnn_gather_rows": (c_int32, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "mpnn_aggregate_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
                                      c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
-                                     c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
-                                     c_int32, c_void_p]),
+                                     c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                     c_int64, c_int32, c_int32, c_void_p]),
+    "mpnn_count_fixup": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                   c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_aggregate_fwd_noalloc": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int32, c_void_p,
                                              c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64,
-                                             c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
-                                             c_int32, c_void_p]),
+                                             c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                             c_int32, c_int32, c_void_p]),
     "mpnn_bwd_scratch_floats": (c_int64, [c_int32, c_int32]),
     "mpnn_mask_words": (c_int32, [c_int32, c_int32]),
     "mpnn_aggregate_bwd_src_masked": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
@@ -91,11 +94,11 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_gemm_nt_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
-                                   c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int32,
+                                   c_void_p, c_int64, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_int64, c_int32,
                                    c_int32, c_void_p, c_void_p]),
     "mpnn_gemm_nt_scratch_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "mpnn_gemm_nt_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p,
-                                    c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                    c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_void_p, c_int64,
                                     c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_gemm_tn_scratch_floats": (c_int64, [c_int64, c_int32, c_int32]),
     "mpnn_gemm_tn_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,

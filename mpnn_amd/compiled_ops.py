@@ -8,8 +8,8 @@ whose backward is again one operator, and finds the sorted structure of ``edge_i
 eager path uses - the cache stays outside the traced region, keyed on the tensor as before.  Eager calls and
 compiled calls run the same sequence of library kernels and return the same bits.
 
-  mpnn_amd::layer_fwd   (x, edge_index, edge_attr, w_nodes, w_edge, w_out, train) -> (y, ab, aggr, cnt, maskbits)
-  mpnn_amd::layer_bwd   (gy, x, edge_index, edge_attr, ab, aggr, cnt, maskbits, y, weights..., needs...) -> 4 gradients
+  mpnn_amd::layer_fwd   (x, edge_index, edge_attr, w_nodes, w_edge, w_out, train) -> (y, ab, aggr, cnt, cnt_big, maskbits)
+  mpnn_amd::layer_bwd   (gy, x, edge_index, edge_attr, ab, aggr, cnt, cnt_big, maskbits, y, weights..., needs...) -> 4 gradients
   mpnn_amd::mean_pool / mean_pool_bwd                     global_mean_pool (models/mpnn.py:54,150)
 """
 from __future__ import annotations
@@ -29,17 +29,20 @@ def _mask_words(h: int, dtype) -> int:
 
 @torch.library.custom_op("mpnn_amd::layer_fwd", mutates_args=(), device_types="cuda")
 def layer_fwd(x: Tensor, edge_index: Tensor, edge_attr: Tensor, w_nodes: Tensor, w_edge: Tensor, w_out: Tensor,
-              train: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor]:
+              train: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor, Tensor, Tensor]:
     graph = graph_for(edge_index, x.size(0))
     x = x if x.is_contiguous() and x.data_ptr() % 16 == 0 else x.clone(memory_format=torch.contiguous_format)
     y, ab, aggr, cnt, maskbits, _ = layer_fn.forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, train)
     h = w_out.size(0)
+    cnt, cnt_big = cnt if cnt is not None else (None, None)
     if cnt is None:
-        cnt = torch.empty((0, h), dtype=torch.float32, device=x.device)
+        cnt = torch.empty((0, h), dtype=torch.uint8, device=x.device)
+    if cnt_big is None:
+        cnt_big = torch.empty((0, h), dtype=torch.float32, device=x.device)
     if maskbits is None:
         maskbits = torch.empty((edge_index.size(1) if train else 0, _mask_words(h, x.dtype) if train else 0),
                                dtype=torch.int32, device=x.device)
-    return y, ab, aggr, cnt, maskbits
+    return y, ab, aggr, cnt, cnt_big, maskbits
 
 
 @layer_fwd.register_fake
@@ -48,28 +51,32 @@ def _(x, edge_index, edge_attr, w_nodes, w_edge, w_out, train):
     y = x.new_empty((n, h))
     ab = x.new_empty((n, 2 * h))
     aggr = x.new_empty((n, h))
-    cnt = x.new_empty((n if train else 0, h), dtype=torch.float32)
+    cnt = x.new_empty((n if train else 0, h), dtype=torch.uint8)
+    # exact counts of the rows longer than a byte can count: as many rows as the graph has such rows
+    long_rows = torch.library.get_ctx().new_dynamic_size() if train else 0
+    cnt_big = x.new_empty((long_rows, h), dtype=torch.float32)
     maskbits = x.new_empty((edge_index.size(1) if train else 0, _mask_words(h, x.dtype) if train else 0),
                            dtype=torch.int32)
-    return y, ab, aggr, cnt, maskbits
+    return y, ab, aggr, cnt, cnt_big, maskbits
 
 
 @torch.library.custom_op("mpnn_amd::layer_bwd", mutates_args=(), device_types="cuda")
 def layer_bwd(gy: Tensor, x: Tensor, edge_index: Tensor, edge_attr: Tensor, ab: Tensor, aggr: Tensor, cnt: Tensor,
-              maskbits: Tensor, y: Tensor, w_nodes: Tensor, w_edge: Tensor, w_out: Tensor, need_x: bool, need_wn: bool,
+              cnt_big: Tensor, maskbits: Tensor, y: Tensor, w_nodes: Tensor, w_edge: Tensor, w_out: Tensor, need_x: bool, need_wn: bool,
               need_we: bool, need_wout: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     graph = graph_for(edge_index, x.size(0))
     ea_t = graph.sorted_edge_attr(edge_attr, x.dtype)[1]
     x = x if x.is_contiguous() and x.data_ptr() % 16 == 0 else x.clone(memory_format=torch.contiguous_format)
     bits = maskbits if maskbits.size(1) > 0 else None
-    grads = layer_fn.backward_impl(gy, x, ab, aggr, cnt, bits, y, ea_t, w_nodes, w_edge, w_out, graph,
+    counts = (cnt, cnt_big if cnt_big.size(0) > 0 else None)
+    grads = layer_fn.backward_impl(gy, x, ab, aggr, counts, bits, y, ea_t, w_nodes, w_edge, w_out, graph,
                                    (need_x, need_wn, need_we, need_wout))
     none = lambda like: like.new_empty((0,))
     return tuple(g if g is not None else none(x) for g in grads)
 
 
 @layer_bwd.register_fake
-def _(gy, x, edge_index, edge_attr, ab, aggr, cnt, maskbits, y, w_nodes, w_edge, w_out, need_x, need_wn, need_we,
+def _(gy, x, edge_index, edge_attr, ab, aggr, cnt, cnt_big, maskbits, y, w_nodes, w_edge, w_out, need_x, need_wn, need_we,
       need_wout):
     e = lambda like, on: torch.empty_like(like, memory_format=torch.contiguous_format) if on else x.new_empty((0,))
     return e(x, need_x), e(w_nodes, need_wn), e(w_edge, need_we), e(w_out, need_wout)
@@ -77,10 +84,10 @@ def _(gy, x, edge_index, edge_attr, ab, aggr, cnt, maskbits, y, w_nodes, w_edge,
 
 def _layer_setup(ctx, inputs, output):
     x, edge_index, edge_attr, w_nodes, w_edge, w_out, train = inputs
-    y, ab, aggr, cnt, maskbits = output
+    y, ab, aggr, cnt, cnt_big, maskbits = output
     ctx.set_materialize_grads(False)
     ctx.train = train
-    ctx.save_for_backward(x, edge_index, edge_attr, ab, aggr, cnt, maskbits, y, w_nodes, w_edge, w_out)
+    ctx.save_for_backward(x, edge_index, edge_attr, ab, aggr, cnt, cnt_big, maskbits, y, w_nodes, w_edge, w_out)
 
 
 def _layer_backward(ctx, gy, *unused):

@@ -32,6 +32,26 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // gathered rows, some of which are re-read often (targets of high in-degree), keep the L2.
 #define NT_LOAD(p) __builtin_nontemporal_load(p)
 
+// VEC counts as bytes (saturated at 255): one 4- or 8-byte store when the lane owns that many columns.
+template <int VEC>
+__device__ __forceinline__ void store_count_bytes(uint8_t* p, const int (&cn)[VEC]) {
+  if constexpr (VEC % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+      uint32_t w = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = cn[4 * q + k];
+        w |= (uint32_t)(c > 255 ? 255 : c) << (8 * k);
+      }
+      reinterpret_cast<uint32_t*>(p)[q] = w;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) p[v] = (uint8_t)(cn[v] > 255 ? 255 : cn[v]);
+  }
+}
+
 template <typename T>
 struct FwdArgs {
   const T* A; int64_t ldA;
@@ -41,7 +61,11 @@ struct FwdArgs {
   const int32_t* col;
   const int4* items; int64_t n_items;
   T* out; int64_t ldo;
-  float* cnt;
+  uint8_t* cnt;        // [N][H] bytes: positive messages per target row and column, saturated at 255
+  float* cnt_big;      // [n_split + n_big][H]: the exact counts of the rows that can exceed 255 (see mpnn_amd.h)
+  int64_t first_plain; // index of the first item of an unsplit row (= number of partial slots)
+  int64_t n_big;       // unsplit rows with more than 255 edges: the items first_plain .. first_plain + n_big - 1
+  int64_t n_split;
   float* part_out;
   float* part_cnt;
   uint32_t* maskbits;  // optional [E][mpnn_mask_words] words: bit `lig` of word v = (message column lig*VEC+v of this
@@ -173,10 +197,13 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
       if (it.w < 0) {
         RowIO<T, VEC>::store(a.out + (int64_t)row * a.ldo + c0, acc);
         if (TRAIN) {
-          float cf[VEC];
+          store_count_bytes<VEC>(a.cnt + (int64_t)row * a.H + c0, cn);
+          if (t < a.first_plain + a.n_big) {   // a long unsplit row: its exact counts go to the side table
+            float cf[VEC];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v) cf[v] = (float)cn[v];
-          store_f32<VEC>(a.cnt + (int64_t)row * a.H + c0, cf);
+            for (int v = 0; v < VEC; ++v) cf[v] = (float)cn[v];
+            store_f32<VEC>(a.cnt_big + (a.n_split + (t - a.first_plain)) * a.H + c0, cf);
+          }
         }
       } else {
         float* po = a.part_out + (int64_t)it.w * a.H + c0;
@@ -398,6 +425,22 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a)
   block_reduce_lane_partials<VEC, FE>(gw, lds, a.gwe_partial, a.H, a.fe, a.lpr_log2);
 }
 
+// gA[row, :] = G[row, :] * cnt_big[slot, :] for the rows whose counts can exceed a byte: slot s < n_split is the
+// row of split record s, slot n_split + j the row of item first_plain + j (the longest unsplit rows).
+template <typename T>
+__global__ void __launch_bounds__(kBlock) k_count_fixup(const T* __restrict__ G, int64_t ldG,
+                                                        const float* __restrict__ cnt_big,
+                                                        const int4* __restrict__ items, const int4* __restrict__ split,
+                                                        int64_t n_split, int64_t first_plain, int64_t n_big,
+                                                        T* __restrict__ gA, int64_t ldgA, int H) {
+  const int64_t slots = n_split + n_big;
+  for (int64_t s = blockIdx.x; s < slots; s += gridDim.x) {
+    const int64_t row = s < n_split ? split[s].x : items[first_plain + (s - n_split)].x;
+    for (int c = threadIdx.x; c < H; c += kBlock)
+      gA[row * ldgA + c] = f32_to_scalar<T>(scalar_to_f32<T>(G[row * ldG + c]) * cnt_big[s * H + c]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Segment mean (global_mean_pool, models/mpnn.py:54,150): one block per segment.
 // ---------------------------------------------------------------------------------------
@@ -503,8 +546,9 @@ static int32_t launch_fwd(const FwdArgs<T>& a, dim3 grid, hipStream_t stream) {
 template <typename T, int VEC>
 static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea, int32_t Fe,
                        const void* We, const int32_t* col, const int32_t* items, int64_t n_items,
-                       const int32_t* split, int64_t n_split, void* out, int64_t ldo, float* cnt, float* part_out,
-                       float* part_cnt, uint32_t* maskbits, int32_t H, const Geometry& g, hipStream_t stream) {
+                       const int32_t* split, int64_t n_split, int64_t n_parts, void* out, int64_t ldo, uint8_t* cnt,
+                       float* cnt_big, int64_t n_big, float* part_out, float* part_cnt, uint32_t* maskbits, int32_t H,
+                       const Geometry& g, hipStream_t stream) {
   FwdArgs<T> a;
   a.A = static_cast<const T*>(A); a.ldA = ldA;
   a.B = static_cast<const T*>(B); a.ldB = ldB;
@@ -513,7 +557,8 @@ static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, c
   a.col = col;
   a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
   a.out = static_cast<T*>(out); a.ldo = ldo;
-  a.cnt = cnt; a.part_out = part_out; a.part_cnt = part_cnt;
+  a.cnt = cnt; a.cnt_big = cnt_big; a.first_plain = n_parts; a.n_big = n_big; a.n_split = n_split;
+  a.part_out = part_out; a.part_cnt = part_cnt;
   a.maskbits = maskbits;
   a.H = H; a.lpr_log2 = g.lpr_log2;
   // One item per lane group while the grid allows it: the items arrive largest first, so the hardware's
@@ -530,7 +575,8 @@ static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, c
   if (n_split > 0) {
     rc = launch_reduce_split<T, VEC>(part_out, split, n_split, static_cast<T*>(out), ldo, H, g, stream);
     if (rc != MPNN_OK) return rc;
-    if (cnt) rc = launch_reduce_split<float, VEC>(part_cnt, split, n_split, cnt, H, H, g, stream);
+    // the exact counts of split rows go to the side table, one row per split record
+    if (cnt) rc = launch_reduce_split<float, VEC>(part_cnt, split, n_split, cnt_big, H, H, g, stream, /*by_slot=*/true);
   }
   return rc;
 }
@@ -649,10 +695,12 @@ extern "C" {
 
 int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea_sorted, int32_t Fe,
                            const void* We, const int32_t* col, const int32_t* items, int64_t n_items,
-                           const int32_t* split, int64_t n_split, int64_t n_parts, void* out, int64_t ldo, float* cnt,
-                           float* part_out, float* part_cnt, uint32_t* maskbits, int64_t num_nodes, int32_t H,
-                           int32_t dtype, mpnn_stream_t stream) {
+                           const int32_t* split, int64_t n_split, int64_t n_parts, void* out, int64_t ldo, uint8_t* cnt,
+                           float* cnt_big, int64_t n_big, float* part_out, float* part_cnt, uint32_t* maskbits,
+                           int64_t num_nodes, int32_t H, int32_t dtype, mpnn_stream_t stream) {
   if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: dtype %d", dtype);
+  if (n_big < 0 || (cnt && n_split + n_big > 0 && !cnt_big))
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: %lld long rows but no cnt_big table", (long long)(n_split + n_big));
   if (H < 1 || Fe < 1 || Fe > kMaxFe)
     return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: H=%d (>=1), Fe=%d (1..%d)", H, Fe, kMaxFe);
   if (num_nodes < 0 || n_items < 0 || n_split < 0 || n_parts < 0)
@@ -665,23 +713,23 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
   if (((uintptr_t)items & 15) || ((uintptr_t)split & 15))
     return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: items/split must be 16-byte aligned");
   const int full = dtype == MPNN_BF16 ? 8 : 4;
-  const bool vec_ok = aligned16(A) && aligned16(B) && aligned16(out) && aligned16(cnt) && aligned16(ea_sorted) &&
-                      ldA % full == 0 && ldB % full == 0 && ldo % full == 0;
+  const bool vec_ok = aligned16(A) && aligned16(B) && aligned16(out) && aligned16(cnt) && aligned16(cnt_big) &&
+                      aligned16(ea_sorted) && ldA % full == 0 && ldB % full == 0 && ldo % full == 0;
   const Geometry g = geometry(H, dtype, vec_ok);
   if (maskbits && (!cnt || g.vec == 1 || g.tiles != 1 || g.lpr_log2 > 5 || ((uintptr_t)maskbits & 15)))
     return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: maskbits needs cnt, the vector path and mpnn_mask_words(H, dtype) > 0");
   if (dtype == MPNN_F32) {
     if (g.vec == 4)
-      return run_fwd<float, 4>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                               part_out, part_cnt, maskbits, H, g, stream);
-    return run_fwd<float, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                             part_out, part_cnt, maskbits, H, g, stream);
+      return run_fwd<float, 4>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, n_parts, out, ldo,
+                               cnt, cnt_big, n_big, part_out, part_cnt, maskbits, H, g, stream);
+    return run_fwd<float, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, n_parts, out, ldo, cnt,
+                             cnt_big, n_big, part_out, part_cnt, maskbits, H, g, stream);
   }
   if (g.vec == 8)
-    return run_fwd<bf16_t, 8>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                              part_out, part_cnt, maskbits, H, g, stream);
-  return run_fwd<bf16_t, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, out, ldo, cnt,
-                            part_out, part_cnt, maskbits, H, g, stream);
+    return run_fwd<bf16_t, 8>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, n_parts, out, ldo,
+                              cnt, cnt_big, n_big, part_out, part_cnt, maskbits, H, g, stream);
+  return run_fwd<bf16_t, 1>(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, n_parts, out, ldo, cnt,
+                            cnt_big, n_big, part_out, part_cnt, maskbits, H, g, stream);
 }
 
 }  // extern "C"
@@ -722,8 +770,8 @@ extern "C" {
 int32_t mpnn_aggregate_fwd_noalloc(const void* A, int64_t ldA, const void* B, int64_t ldB, const void* ea_sorted,
                                    int32_t Fe, const void* We, const int32_t* col, const int32_t* items,
                                    int64_t n_items, const int32_t* split, int64_t n_split, int64_t n_parts, void* out,
-                                   int64_t ldo, float* cnt, uint32_t* maskbits, int64_t num_nodes, int32_t H,
-                                   int32_t dtype, mpnn_stream_t stream) {
+                                   int64_t ldo, uint8_t* cnt, float* cnt_big, int64_t n_big, uint32_t* maskbits,
+                                   int64_t num_nodes, int32_t H, int32_t dtype, mpnn_stream_t stream) {
   if (H < 1 || n_parts < 0) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd_noalloc: H=%d n_parts=%lld", H, (long long)n_parts);
   float* part_out = nullptr;
   float* part_cnt = nullptr;
@@ -745,7 +793,35 @@ int32_t mpnn_aggregate_fwd_noalloc(const void* A, int64_t ldA, const void* B, in
     part_cnt = cnt ? base + slab : nullptr;
   }
   return mpnn_aggregate_fwd(A, ldA, B, ldB, ea_sorted, Fe, We, col, items, n_items, split, n_split, n_parts, out, ldo,
-                            cnt, part_out, part_cnt, maskbits, num_nodes, H, dtype, stream);
+                            cnt, cnt_big, n_big, part_out, part_cnt, maskbits, num_nodes, H, dtype, stream);
+}
+
+int32_t mpnn_count_fixup(const void* G, int64_t ldG, const float* cnt_big, const int32_t* items, const int32_t* split,
+                         int64_t n_split, int64_t n_parts, int64_t n_big, void* gA, int64_t ldgA, int32_t H,
+                         int32_t dtype, mpnn_stream_t stream) {
+  if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "mpnn_count_fixup: dtype %d", dtype);
+  if (H < 1 || n_split < 0 || n_parts < 0 || n_big < 0 || ldG < H || ldgA < H)
+    return fail(MPNN_E_INVALID, "mpnn_count_fixup: H=%d n_split=%lld n_big=%lld ldG=%lld ldgA=%lld", H,
+                (long long)n_split, (long long)n_big, (long long)ldG, (long long)ldgA);
+  const int64_t slots = n_split + n_big;
+  if (slots == 0) return MPNN_OK;
+  if (!G || !cnt_big || !gA || (n_split > 0 && !split) || (n_big > 0 && !items))
+    return fail(MPNN_E_INVALID, "mpnn_count_fixup: null pointer argument");
+  if (((uintptr_t)items & 15) || ((uintptr_t)split & 15))
+    return fail(MPNN_E_INVALID, "mpnn_count_fixup: items/split must be 16-byte aligned");
+  const int blocks = (int)(slots < kMaxBlocks ? slots : kMaxBlocks);
+  if (dtype == MPNN_F32)
+    k_count_fixup<float><<<blocks, kBlock, 0, stream>>>(static_cast<const float*>(G), ldG, cnt_big,
+                                                        reinterpret_cast<const int4*>(items),
+                                                        reinterpret_cast<const int4*>(split), n_split, n_parts, n_big,
+                                                        static_cast<float*>(gA), ldgA, H);
+  else
+    k_count_fixup<bf16_t><<<blocks, kBlock, 0, stream>>>(static_cast<const bf16_t*>(G), ldG, cnt_big,
+                                                         reinterpret_cast<const int4*>(items),
+                                                         reinterpret_cast<const int4*>(split), n_split, n_parts, n_big,
+                                                         static_cast<bf16_t*>(gA), ldgA, H);
+  MPNN_LAUNCH_CHECK("k_count_fixup");
+  return MPNN_OK;
 }
 
 int32_t mpnn_mask_words(int32_t H, int32_t dtype) {

@@ -95,7 +95,7 @@ __device__ __forceinline__ void block_reduce_lane_partials(const float (&gw)[VEC
 template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock) k_reduce_split(const float* __restrict__ parts, const int4* __restrict__ split,
                                                          int64_t n_split, T* __restrict__ out, int64_t ldo, int H,
-                                                         int lpr_log2) {
+                                                         int lpr_log2, bool by_slot) {
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << lpr_log2;
   const int lig = lane & (lpr - 1);
@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(kBlock) k_reduce_split(const float* __restrict
   const int64_t nwaves = (int64_t)gridDim.x * (kBlock / 64);
   for (int64_t s = wave; s < n_split; s += nwaves) {
     const int4 sr = split[s];
-    const int row = sr.x, poff = sr.y, pieces = sr.z;
+    const int64_t row = by_slot ? s : (int64_t)sr.x;   // by_slot: a table with one row per split record
+    const int poff = sr.y, pieces = sr.z;
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(kBlock) k_reduce_split(const float* __restrict
       for (int v = 0; v < VEC; ++v) tot[v] += __shfl(acc[v], g * lpr + lig, 64);
     }
     if (grp == 0 && act) {
-      T* o = out + (int64_t)row * ldo + c0;
+      T* o = out + row * ldo + c0;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) o[v] = f32_to_scalar<T>(tot[v]);
     }
@@ -184,11 +185,11 @@ inline int row_grid(int64_t n_items, int lpr_log2, int64_t max_blocks = kMaxBloc
 
 template <typename T, int VEC>
 inline int32_t launch_reduce_split(const float* parts, const int32_t* split, int64_t n_split, T* out, int64_t ldo,
-                                   int H, const Geometry& g, hipStream_t stream) {
+                                   int H, const Geometry& g, hipStream_t stream, bool by_slot = false) {
   int64_t blocks = (n_split + 3) / 4;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
   k_reduce_split<T, VEC><<<dim3((unsigned)blocks, g.tiles), kBlock, 0, stream>>>(
-      parts, reinterpret_cast<const int4*>(split), n_split, out, ldo, H, g.lpr_log2);
+      parts, reinterpret_cast<const int4*>(split), n_split, out, ldo, H, g.lpr_log2, by_slot);
   MPNN_LAUNCH_CHECK("k_reduce_split");
   return MPNN_OK;
 }

@@ -42,6 +42,7 @@ struct NtArgs {
   int nseg;
   float* Y; int64_t ldy;
   const float* emul; int64_t ldemul;  // optional [N, M]: second output Y2 = Y * emul
+  const uint8_t* emul8;               // the same factor stored as bytes (emul is null then)
   float* Y2; int64_t ldy2;
   int64_t N; int M;
   int relu;
@@ -396,7 +397,13 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
           if (row < a.N && col < a.M) {
             *reinterpret_cast<float4*>(a.Y + row * a.ldy + col) = v;
             if (a.Y2) {
-              const float4 e = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
+              float4 e;
+              if (a.emul8) {   // uniform over the launch
+                const uint32_t w = *reinterpret_cast<const uint32_t*>(a.emul8 + row * a.ldemul + col);
+                e = make_float4((float)(w & 255u), (float)((w >> 8) & 255u), (float)((w >> 16) & 255u), (float)(w >> 24));
+              } else {
+                e = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
+              }
               *reinterpret_cast<float4*>(a.Y2 + row * a.ldy2 + col) = make_float4(v.x * e.x, v.y * e.y, v.z * e.z, v.w * e.w);
             }
           }
@@ -436,7 +443,9 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
               if (a.relu) v = v <= 0.f ? 0.f : v;
               a.Y[row * a.ldy + col] = v;
               if constexpr (WITH_Y2) {
-                if (a.Y2) a.Y2[row * a.ldy2 + col] = v * a.emul[row * a.ldemul + col];
+                if (a.Y2)
+                  a.Y2[row * a.ldy2 + col] =
+                      v * (a.emul8 ? (float)a.emul8[row * a.ldemul + col] : a.emul[row * a.ldemul + col]);
               }
             }
             acc[t][r] = 0.f;
@@ -1127,7 +1136,7 @@ static void launch_nt(NtArgs& a, bool aligned, hipStream_t stream) {
   dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
   // LDS-staged epilogue only for the three-array case, and only when 16-byte accesses are legal
   const bool staged = a.Y2 && (a.M & 3) == 0 && ((a.ldy | a.ldy2 | a.ldemul) & 3) == 0 &&
-                      (((uintptr_t)a.Y | (uintptr_t)a.Y2 | (uintptr_t)a.emul) & 15) == 0;
+                      (((uintptr_t)a.Y | (uintptr_t)a.Y2 | (uintptr_t)a.emul | (uintptr_t)a.emul8) & 15) == 0;
   const bool has_mask = a.seg[0].mask || (a.nseg > 1 && a.seg[1].mask);
   auto go = [&](auto kern, size_t lds) { kern<<<grid, kBlock * WC, lds, stream>>>(a); };
   constexpr size_t kPatches = (size_t)4 * WC * 32 * 36 * sizeof(float);   // one 32 x 32 patch (pitch 36) per wave
@@ -1176,9 +1185,10 @@ extern "C" {
 
 int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int64_t ldm1, const float* W1,
                          int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2, const float* mask2, int64_t ldm2,
-                         const float* W2, int64_t ldw2, int32_t K2, float* Y, int64_t ldy, const float* emul,
-                         int64_t ldemul, float* Y2, int64_t ldy2, int64_t N, int32_t M, int32_t relu,
-                         void* scratch, mpnn_stream_t stream) {
+                         const float* W2, int64_t ldw2, int32_t K2, float* Y, int64_t ldy, const void* emul,
+                         int32_t emul_kind, int64_t ldemul, float* Y2, int64_t ldy2, int64_t N, int32_t M,
+                         int32_t relu, void* scratch, mpnn_stream_t stream) {
+  if (emul_kind != MPNN_F32 && emul_kind != MPNN_U8) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: emul_kind %d", emul_kind);
   if (N < 0 || M < 1 || K1 < 1 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: bad sizes");
   if (N == 0) return MPNN_OK;
   if (!X1 || !W1 || !Y || (K2 > 0 && (!X2 || !W2))) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: null pointer argument");
@@ -1189,7 +1199,9 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
   a.seg[1] = NtSegment{X2, ldx2, mask2, ldm2, W2, ldw2, K2};
   a.nseg = K2 > 0 ? 2 : 1;
   if (Y2 && (!emul || ldemul < M || ldy2 < M)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: Y2 needs emul and ld >= M");
-  a.Y = Y; a.ldy = ldy; a.emul = emul; a.ldemul = ldemul; a.Y2 = Y2; a.ldy2 = ldy2;
+  a.Y = Y; a.ldy = ldy; a.ldemul = ldemul; a.Y2 = Y2; a.ldy2 = ldy2;
+  a.emul = emul_kind == MPNN_F32 ? static_cast<const float*>(emul) : nullptr;
+  a.emul8 = emul_kind == MPNN_U8 ? static_cast<const uint8_t*>(emul) : nullptr;
   a.N = N; a.M = M; a.relu = relu;
   if (scratch && ((uintptr_t)scratch & 15)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: scratch must be 16-byte aligned");
   a.wimg = static_cast<const char*>(scratch);

@@ -37,6 +37,7 @@ struct NtBf16Args {
   int nseg;
   bf16_t* Y; int64_t ldy;
   const float* emul; int64_t ldemul;   // optional [N, M] float32: second output Y2 = Y * emul
+  const uint8_t* emul8;                // the same factor stored as bytes (emul is null then)
   bf16_t* Y2; int64_t ldy2;
   int64_t N; int M;
   int relu;
@@ -198,8 +199,15 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt_bf16(NtBf16Args a) {
           if (row < a.N && col < a.M) {   // M is a multiple of 8: a lane's 8 columns are inside or outside
             *reinterpret_cast<uint4*>(a.Y + row * a.ldy + col) =
                 make_uint4(pack2_bf16(v0.x, v0.y), pack2_bf16(v0.z, v0.w), pack2_bf16(v1.x, v1.y), pack2_bf16(v1.z, v1.w));
-            const float4 e0 = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
-            const float4 e1 = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col + 4);
+            float4 e0, e1;
+            if (a.emul8) {   // uniform over the launch
+              const uint2 w = *reinterpret_cast<const uint2*>(a.emul8 + row * a.ldemul + col);
+              e0 = make_float4((float)(w.x & 255u), (float)((w.x >> 8) & 255u), (float)((w.x >> 16) & 255u), (float)(w.x >> 24));
+              e1 = make_float4((float)(w.y & 255u), (float)((w.y >> 8) & 255u), (float)((w.y >> 16) & 255u), (float)(w.y >> 24));
+            } else {
+              e0 = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col);
+              e1 = *reinterpret_cast<const float4*>(a.emul + row * a.ldemul + col + 4);
+            }
             *reinterpret_cast<uint4*>(a.Y2 + row * a.ldy2 + col) =
                 make_uint4(pack2_bf16(v0.x * e0.x, v0.y * e0.y), pack2_bf16(v0.z * e0.z, v0.w * e0.w),
                            pack2_bf16(v1.x * e1.x, v1.y * e1.y), pack2_bf16(v1.z * e1.z, v1.w * e1.w));
@@ -455,8 +463,10 @@ using namespace mpnn;
 
 extern "C" int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W1, int64_t ldw1, int32_t K1,
                                      const void* X2, int64_t ldx2, const void* W2, int64_t ldw2, int32_t K2, void* Y,
-                                     int64_t ldy, const float* emul, int64_t ldemul, void* Y2, int64_t ldy2,
-                                     int64_t N, int32_t M, int32_t relu, mpnn_stream_t stream) {
+                                     int64_t ldy, const void* emul, int32_t emul_kind, int64_t ldemul, void* Y2,
+                                     int64_t ldy2, int64_t N, int32_t M, int32_t relu, mpnn_stream_t stream) {
+  if (emul_kind != MPNN_F32 && emul_kind != MPNN_U8) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: emul_kind %d", emul_kind);
+  if (emul_kind == MPNN_U8 && (ldemul & 7)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: byte emul rows must be 8-byte aligned");
   if (N < 0 || M < 8 || K1 < 8 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: bad sizes");
   if ((M | K1 | K2) & 7) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_bf16: M, K1 and K2 must be multiples of 8");
   if (N == 0) return MPNN_OK;
@@ -474,7 +484,9 @@ extern "C" int32_t mpnn_gemm_nt_bf16(const void* X1, int64_t ldx1, const void* W
   a.seg[1] = NtBf16Seg{static_cast<const bf16_t*>(X2), ldx2, static_cast<const bf16_t*>(W2), ldw2, K2};
   a.nseg = K2 > 0 ? 2 : 1;
   a.Y = static_cast<bf16_t*>(Y); a.ldy = ldy;
-  a.emul = emul; a.ldemul = ldemul;
+  a.emul = emul_kind == MPNN_F32 ? static_cast<const float*>(emul) : nullptr;
+  a.emul8 = emul_kind == MPNN_U8 ? static_cast<const uint8_t*>(emul) : nullptr;
+  a.ldemul = ldemul;
   a.Y2 = static_cast<bf16_t*>(Y2); a.ldy2 = ldy2;
   a.N = N; a.M = M; a.relu = relu;
   if (M <= 32) launch_nt_bf16<1, 1>(a, stream);

@@ -53,11 +53,20 @@ def _ld(t) -> int:
     return t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
 
 
+def _emul_kind(emul) -> int:
+    """Kind of an epilogue multiplier: float32, or one byte per entry (the counts of the forward edge pass)."""
+    if emul is None or emul.dtype == torch.float32:
+        return _lib.MPNN_F32
+    if emul.dtype == torch.uint8:
+        return _lib.MPNN_U8
+    raise TypeError(f"emul must be float32 or uint8, got {emul.dtype}")
+
+
 def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=None, out2=None) -> torch.Tensor:
     """act(x1 @ w1^T [+ x2 @ w2^T]); maskI > 0 selects the entries of xI that are used.
 
-    With ``emul`` [N, M] and ``out2`` (a [N, M] view with unit column stride) the epilogue also writes
-    out2 = result * emul."""
+    With ``emul`` [N, M] (float32 or uint8) and ``out2`` (a [N, M] view with unit column stride) the epilogue also
+    writes out2 = result * emul."""
     lib = _lib.load()
     x1, w1 = _rows(x1), _rows(w1)
     n, k1 = x1.shape
@@ -75,7 +84,7 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=N
         _lib.ptr(x2), _ld(x2), _lib.ptr(mask2),
         _ld(mask2), _lib.ptr(w2), _ld(w2),
         x2.size(1) if x2 is not None else 0,
-        _lib.ptr(y), _ld(y), _lib.ptr(emul), _ld(emul), _lib.ptr(out2),
+        _lib.ptr(y), _ld(y), _lib.ptr(emul), _emul_kind(emul), _ld(emul), _lib.ptr(out2),
         _ld(out2), n, m, 1 if relu else 0, _lib.ptr(wimg),
         _lib.stream_handle(x1.device)),
         "mpnn_gemm_nt_f32")
@@ -106,7 +115,7 @@ def gemm_nt_bf16(x1, w1, x2=None, w2=None, relu=False, emul=None, out2=None) -> 
         _lib.ptr(x1), _ld(x1), _lib.ptr(w1), _ld(w1), k1,
         _lib.ptr(x2), _ld(x2), _lib.ptr(w2), _ld(w2),
         x2.size(1) if x2 is not None else 0,
-        _lib.ptr(y), _ld(y), _lib.ptr(emul), _ld(emul), _lib.ptr(out2),
+        _lib.ptr(y), _ld(y), _lib.ptr(emul), _emul_kind(emul), _ld(emul), _lib.ptr(out2),
         _ld(out2), n, m, 1 if relu else 0, _lib.stream_handle(x1.device)),
         "mpnn_gemm_nt_bf16")
     return y

@@ -20,6 +20,7 @@ from . import _lib
 CHUNK = 64
 CHUNK_MAX = 1024
 MAX_PARTS = 256
+BYTE_COUNT_MAX = 255    # a target row of at most this many edges has exact one-byte counts of positive messages
 # Edge lists of at least this many edges get their sorted views laid out in work-item order by graph_for()
 # (see MPGraph, ``row_order``).
 ITEM_ORDER_MIN_EDGES = 1 << 22
@@ -37,7 +38,11 @@ class CSR:
     """One sorted view of the edge list (see mpnn_csr_build / mpnn_items_build)."""
 
     __slots__ = ("num_rows", "num_cols", "num_edges", "rowptr", "col", "eid", "items", "split",
-                 "n_items", "n_parts", "n_split", "order")
+                 "n_items", "n_parts", "n_split", "order", "n_big")
+
+    def __init__(self):
+        self.order = None
+        self.n_big = 0      # unsplit rows with more than 255 edges: the first n_big unsplit work items
 
     def degree(self) -> torch.Tensor:
         """Edges per row, indexed by row id."""
@@ -93,7 +98,13 @@ def _build_items(csr: CSR, chunk: int, max_parts: int, status: torch.Tensor, ws:
     _lib.check(lib.mpnn_items_build(_lib.ptr(csr.rowptr), num_rows, chunk, max_parts, _lib.ptr(csr.items),
                                     items_cap, _lib.ptr(csr.split), split_cap, _lib.ptr(meta), _lib.ptr(ws),
                                     ws.numel(), stream), "mpnn_items_build")
-    return torch.cat([meta[:4], status[:1]])
+    # unsplit rows whose per-column counts can exceed a byte (mpnn_aggregate_fwd keeps exact counts for them)
+    if chunk > BYTE_COUNT_MAX:
+        deg = csr.rowptr[1:] - csr.rowptr[:-1]
+        n_big = ((deg > BYTE_COUNT_MAX) & (deg <= chunk)).sum().to(torch.int32).view(1)
+    else:
+        n_big = torch.zeros(1, dtype=torch.int32, device=dev)
+    return torch.cat([meta[:4], status[:1], n_big])
 
 
 def _rows_into_item_order(csr: CSR, status: torch.Tensor, chunk: int) -> None:
@@ -125,7 +136,7 @@ def _finish(csrs, pending) -> None:
             raise IndexError(f"edge_index holds node ids outside [0, {csr.num_rows}) x [0, {csr.num_cols})")
         if h[3] != 0:
             raise _lib.MpnnError("mpnn_items_build overflowed its output capacity")
-        csr.n_items, csr.n_parts, csr.n_split = h[0], h[1], h[2]
+        csr.n_items, csr.n_parts, csr.n_split, csr.n_big = h[0], h[1], h[2], h[5]
 
 
 def _rows_to_ids(csr: CSR) -> None:

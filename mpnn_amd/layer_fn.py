@@ -21,8 +21,9 @@ from .graph import MPGraph
 
 
 def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: bool):
-    """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea_t); cnt / maskbits are None
-    when ``want`` (a backward will follow) is false or no mask layout exists."""
+    """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea_t); cnt = (byte counts, exact
+    counts of the long rows or None) and maskbits are None when ``want`` (a backward will follow) is false, maskbits
+    also when no mask layout exists."""
     bf = x.dtype == torch.bfloat16
     x = x if x.is_contiguous() else x.contiguous()
     f = x.size(1)
@@ -61,7 +62,8 @@ def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_ou
             gemm_tn_bf16(gy, x, mask=y, out=g_wout, g_out=gz, x2=aggr)   # both halves of gW_out in one pass over gy
         else:
             gz = torch.ops.aten.threshold_backward(gy, y, 0)
-        ga = gemm_nt_bf16(gz, wt_out[f:], emul=cnt, out2=g_ab[:, :h])
+        ga = gemm_nt_bf16(gz, wt_out[f:], emul=cnt[0], out2=g_ab[:, :h])
+        ops.count_fixup(ga, cnt, graph.by_dst, g_ab[:, :h])
         g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
         gx = gemm_nt_bf16(gz, wt_out[:f], g_ab, w_nodes.t().contiguous()) if need_x else None
         g_wn = gemm_tn_bf16(g_ab, x) if need_wn else None
@@ -75,7 +77,8 @@ def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_ou
         g, m = gz, None
     elif g_wout is not None:
         gemm_tn(gy, x, mask=y, out=g_wout, x2=aggr)
-    ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt, out2=g_ab[:, :h])
+    ga = gemm_nt(g, wt_out[f:], mask1=m, emul=cnt[0], out2=g_ab[:, :h])
+    ops.count_fixup(ga, cnt, graph.by_dst, g_ab[:, :h])
     g_we = ops._run_backward_src(ab[:, :h], ab[:, h:], ga, ea_t, w_edge, graph.by_src, graph, g_ab[:, h:], maskbits)
     gx = gemm_nt(g, wt_out[:f], g_ab, w_nodes.t().contiguous(), mask1=m) if need_x else None
     g_wn = gemm_tn(g_ab, x) if need_wn else None
@@ -92,15 +95,15 @@ class _LayerFn(torch.autograd.Function):
         x = x if x.is_contiguous() else x.contiguous()
         y, ab, aggr, cnt, maskbits, ea_t = forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, want)
         if want:
-            ctx.save_for_backward(x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out)
+            ctx.save_for_backward(x, ab, aggr, cnt[0], cnt[1], maskbits, y, ea_t, w_nodes, w_edge, w_out)
             ctx.graph = graph
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
+        x, ab, aggr, cnt8, cnt_big, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
         needs = tuple(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
-        gx, g_wn, g_we, g_wout = backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out,
+        gx, g_wn, g_we, g_wout = backward_impl(gy, x, ab, aggr, (cnt8, cnt_big), maskbits, y, ea_t, w_nodes, w_edge, w_out,
                                                ctx.graph, needs)
         return gx, None, g_wn, g_we, g_wout, None
 

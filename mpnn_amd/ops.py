@@ -52,11 +52,15 @@ USE_MASKBITS = os.environ.get("MPNN_NO_MASKBITS", "0") != "1"
 
 
 def _run_forward(A, B, ea_sorted, We, csr: CSR, graph: MPGraph, want_cnt: bool):
+    """mpnn_aggregate_fwd.  Returns (out, counts, maskbits); ``counts`` = (byte counts [N, H], exact float counts of
+    the long rows [n_split + n_big, H] or None) when a backward will follow, else None."""
     lib = _lib.load()
     N, H = A.shape
     dev, dtype = A.device, A.dtype
     out = torch.empty((N, H), dtype=dtype, device=dev)
-    cnt = torch.empty((N, H), dtype=torch.float32, device=dev) if want_cnt else None
+    cnt = torch.empty((N, H), dtype=torch.uint8, device=dev) if want_cnt else None
+    n_long = csr.n_split + csr.n_big
+    cnt_big = torch.empty((n_long, H), dtype=torch.float32, device=dev) if (want_cnt and n_long) else None
     words = lib.mpnn_mask_words(H, _lib.dtype_code(dtype)) if (want_cnt and USE_MASKBITS and csr.num_edges) else 0
     vec = 8 if dtype == torch.bfloat16 else 4
     if words and (A.data_ptr() % 16 or B.data_ptr() % 16 or A.stride(0) % vec or B.stride(0) % vec):
@@ -71,9 +75,27 @@ def _run_forward(A, B, ea_sorted, We, csr: CSR, graph: MPGraph, want_cnt: bool):
         _lib.check(lib.mpnn_aggregate_fwd(
             _lib.ptr(A), A.stride(0), _lib.ptr(B), B.stride(0), _lib.ptr(ea_sorted), ea_sorted.size(1), _lib.ptr(We),
             _lib.ptr(csr.col), _lib.ptr(csr.items), csr.n_items, _lib.ptr(csr.split), csr.n_split, csr.n_parts,
-            _lib.ptr(out), out.stride(0), _lib.ptr(cnt), _lib.ptr(part_out), _lib.ptr(part_cnt), _lib.ptr(maskbits),
-            N, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)), "mpnn_aggregate_fwd")
-    return out, cnt, maskbits
+            _lib.ptr(out), out.stride(0), _lib.ptr(cnt), _lib.ptr(cnt_big), csr.n_big, _lib.ptr(part_out),
+            _lib.ptr(part_cnt), _lib.ptr(maskbits), N, H, _lib.dtype_code(dtype), _lib.stream_handle(dev)),
+            "mpnn_aggregate_fwd")
+    return out, ((cnt, cnt_big) if want_cnt else None), maskbits
+
+
+def count_fixup(g, counts, csr: CSR, g_a) -> None:
+    """g_a[row] = g[row] * (exact count) for the rows whose counts can exceed a byte (after g_a = g * byte counts)."""
+    cnt_big = counts[1]
+    if cnt_big is None:
+        return
+    lib = _lib.load()
+    _lib.check(lib.mpnn_count_fixup(_lib.ptr(g), g.stride(0), _lib.ptr(cnt_big), _lib.ptr(csr.items), _lib.ptr(csr.split),
+                                    csr.n_split, csr.n_parts, csr.n_big, _lib.ptr(g_a), g_a.stride(0), g.size(1),
+                                    _lib.dtype_code(g.dtype), _lib.stream_handle(g.device)), "mpnn_count_fixup")
+
+
+def times_counts(g, counts, csr: CSR, out) -> None:
+    """out = g * counts (elementwise; ``out`` a [N, H] view with unit column stride)."""
+    torch.mul(g, counts[0], out=out)
+    count_fixup(g, counts, csr, out)
 
 
 def _run_backward_src(A, B, G, ea_sorted_t, We, csr_t: CSR, graph: MPGraph, gB, maskbits=None):
@@ -127,22 +149,22 @@ class _AggregateFused(torch.autograd.Function):
         ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
         We_c = We.contiguous()
         want = ctx.needs_input_grad[0] or ctx.needs_input_grad[2]
-        out, cnt, maskbits = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
+        out, counts, maskbits = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
         if want:
             if maskbits is not None:
                 graph.tpos  # built once per graph, outside the backward
-            ctx.save_for_backward(AB, We_c, cnt, ea_t, maskbits)
+            ctx.save_for_backward(AB, We_c, counts[0], counts[1], ea_t, maskbits)
             ctx.graph = graph
         return out
 
     @staticmethod
     def backward(ctx, g):
-        AB, We, cnt, ea_t, maskbits = ctx.saved_tensors
+        AB, We, cnt, cnt_big, ea_t, maskbits = ctx.saved_tensors
         graph = ctx.graph
         H = AB.size(1) // 2
         g = g.contiguous()
         gAB = torch.empty_like(AB)
-        torch.mul(g, cnt, out=gAB[:, :H])  # d out / d A: every edge of row n sees A[n]
+        times_counts(g, (cnt, cnt_big), graph.by_dst, gAB[:, :H])  # d out / d A: every edge of row n sees A[n]
         gWe = _run_backward_src(AB[:, :H], AB[:, H:], g, ea_t, We, graph.by_src, graph, gAB[:, H:], maskbits)
         return gAB, None, gWe, None
 
@@ -155,20 +177,21 @@ class _Aggregate(torch.autograd.Function):
         ea_s, ea_t = _prepare(A, B, edge_attr, We, graph)
         We_c = We.contiguous()
         want = any(ctx.needs_input_grad[i] for i in (0, 1, 3))
-        out, cnt, maskbits = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
+        out, counts, maskbits = _run_forward(A, B, ea_s, We_c, graph.by_dst, graph, want)
         if want:
             if maskbits is not None:
                 graph.tpos
-            ctx.save_for_backward(A, B, We_c, cnt, ea_t, maskbits)
+            ctx.save_for_backward(A, B, We_c, counts[0], counts[1], ea_t, maskbits)
             ctx.graph = graph
         return out
 
     @staticmethod
     def backward(ctx, g):
-        A, B, We, cnt, ea_t, maskbits = ctx.saved_tensors
+        A, B, We, cnt, cnt_big, ea_t, maskbits = ctx.saved_tensors
         graph = ctx.graph
         g = g.contiguous()
-        gA = (g * cnt).to(A.dtype)
+        gA = torch.empty((A.size(0), A.size(1)), dtype=A.dtype, device=A.device)
+        times_counts(g, (cnt, cnt_big), graph.by_dst, gA)
         gB = torch.empty((graph.num_src, A.size(1)), dtype=A.dtype, device=A.device)
         gWe = _run_backward_src(A, B, g, ea_t, We, graph.by_src, graph, gB, maskbits)
         return gA, gB, None, gWe, None

@@ -362,14 +362,15 @@ class _PartitionedLayerFn(torch.autograd.Function):
             if maskbits is not None:
                 graph.tpos
             # the source table is read again only by the backward that recomputes the relu mask
-            ctx.save_for_backward(x, x_all, a, b_all if maskbits is None else None, aggr, cnt, maskbits, y, ea_t,
-                                  w_nodes, w_edge_c, w_out)
+            ctx.save_for_backward(x, x_all, a, b_all if maskbits is None else None, aggr, cnt[0], cnt[1], maskbits, y,
+                                  ea_t, w_nodes, w_edge_c, w_out)
             ctx.graph, ctx.halo = graph, halo
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, x_all, a, b_all, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
+        x, x_all, a, b_all, aggr, cnt8, cnt_big, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
+        cnt = (cnt8, cnt_big)
         graph, halo = ctx.graph, ctx.halo
         nt, tn = _kit(x.dtype)
         bf = x.dtype == torch.bfloat16
@@ -385,7 +386,7 @@ class _PartitionedLayerFn(torch.autograd.Function):
         # the weight-gradient pass that produces gz = gy*[y>0] can wait until the exchange is in flight
         late = (not bf) and need_wout and f % 4 == 0 and h % 4 == 0 and _aligned(gy, y, x, aggr)
         if late:
-            ga = gemm_nt(gy, wt_out[f:], mask1=y, emul=cnt, out2=g_ab[:, :h])
+            ga = gemm_nt(gy, wt_out[f:], mask1=y, emul=cnt8, out2=g_ab[:, :h])
             gz = None
         else:
             if bf and need_wout:
@@ -395,7 +396,8 @@ class _PartitionedLayerFn(torch.autograd.Function):
                 gz = torch.ops.aten.threshold_backward(gy, y, 0)
                 if need_wout:
                     tn(gz, x, out=g_wout, x2=aggr)
-            ga = nt(gz, wt_out[f:], emul=cnt, out2=g_ab[:, :h])
+            ga = nt(gz, wt_out[f:], emul=cnt8, out2=g_ab[:, :h])
+        ops.count_fixup(ga, cnt, graph.by_dst, g_ab[:, :h])
         g_table = torch.empty((graph.num_src, h), dtype=x.dtype, device=x.device)
         g_we = ops._run_backward_src(a, b_all, ga, ea_t, w_edge, graph.by_src, graph, g_table, maskbits)
         pending = halo.start_scatter(g_table) if x_all is None else None

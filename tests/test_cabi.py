@@ -41,13 +41,13 @@ def test_argument_validation_reports_errors_without_a_gpu():
     lib = _lib.load()
     # bad dtype / bad sizes are rejected before any HIP call
     rc = lib.mpnn_aggregate_fwd(None, 0, None, 0, None, 4, None, None, None, 1, None, 0, 0, None, 0, None, None,
-                                None, None, 1, 64, 7, None)
+                                0, None, None, None, 1, 64, 7, None)
     assert rc == -1 and b"dtype" in lib.mpnn_last_error()
     rc = lib.mpnn_aggregate_fwd(None, 0, None, 0, None, 99, None, None, None, 1, None, 0, 0, None, 0, None, None,
-                                None, None, 1, 64, 0, None)
+                                0, None, None, None, 1, 64, 0, None)
     assert rc == -1 and b"Fe" in lib.mpnn_last_error()
     rc = lib.mpnn_aggregate_fwd(None, 64, None, 64, None, 4, None, None, None, 1, None, 0, 0, None, 64, None, None,
-                                None, None, 1, 64, 0, None)
+                                0, None, None, None, 1, 64, 0, None)
     assert rc == -1 and b"null" in lib.mpnn_last_error()
     rc = lib.mpnn_gather_rows(None, None, None, 4, 3, None)
     assert rc == -1

@@ -196,6 +196,84 @@ def test_aggregate_fwd_bwd_fp32(n, e, H, Fe, skew, dev):
     assert_close(got[2], want[2], RTOL32, what="grad We")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_counts_of_rows_longer_than_a_byte_can_count(dtype, dev):
+    """The forward stores the per-column count of positive messages as one byte; rows of more than 255 edges (split
+    rows, and unsplit rows when the pieces are longer than 255 edges) keep exact counts in a side table that
+    mpnn_count_fixup applies after the GEMM epilogue multiplied by the bytes.  Messages are made positive almost
+    everywhere so that the counts really pass 255."""
+    from mpnn_amd import MPNNLayerSum
+    from mpnn_amd.graph import MPGraph, clear_cache, register_graph
+    from mpnn_amd.ops import aggregate_fused
+    gen = torch.Generator().manual_seed(77)
+    n, H, Fe = 400, 64, 4
+    degs = [2000, 700, 511, 400, 300, 257, 256, 255, 254] + [7] * 200       # chunk 512: 2 split rows, 5 long unsplit rows
+    dst = torch.cat([torch.full((d,), i) for i, d in enumerate(degs)])
+    dst = dst[torch.randperm(dst.numel(), generator=gen)]
+    e = dst.numel()
+    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), dst])
+    graph = MPGraph(ei.to(dev), n, chunk=512)
+    assert graph.by_dst.n_split == 2 and graph.by_dst.n_big == 5
+    rtol = RTOL32 if dtype == torch.float32 else RTOL16
+    rnd = (lambda *s: torch.randn(*s, generator=gen).to(dtype).float())
+
+    # the bare operator
+    ab = rnd(n, 2 * H) * 0.3 + 1.0                      # positive pre-activations: counts close to the degrees
+    ea, we, r = torch.rand(e, Fe, generator=gen).to(dtype).float(), rnd(H, Fe) * 0.1, rnd(n, H)
+    # float64 oracle: the float32 CPU sum of 2,000 equal-signed terms is itself 2e-5 off, the GPU's count * g is exact
+    ab_c, we_c = ab.double().requires_grad_(True), we.double().requires_grad_(True)
+    want = O.aggregate_sum_form(ab_c[:, :H], ab_c[:, H:], ea.double(), we_c, ei)
+    (want * r.double()).sum().backward()
+    ab_g, we_g = ab.to(dev, dtype).requires_grad_(True), we.to(dev, dtype).requires_grad_(True)
+    got = aggregate_fused(ab_g, ea.to(dev, dtype), we_g, graph)
+    (got.float() * r.to(dev)).sum().backward()
+    assert_close(got.float(), want, rtol, what="out")
+    assert_close(ab_g.grad.float(), ab_c.grad, rtol, what="grad AB (counts up to 2000)")
+    assert float(ab_c.grad[:7, :H].abs().max()) > 0
+
+    # the whole layer: the byte counts ride on the epilogue of the GEMM, the fix-up follows it
+    clear_cache()
+    ei_d = ei.to(dev)
+    register_graph(ei_d, n, graph)
+    torch.manual_seed(5)
+    layer = MPNNLayerSum(16, Fe, H)
+    with torch.no_grad():
+        layer.fused_linear.weight.mul_(0.05).add_(0.08)       # mostly positive projections
+        for p in layer.parameters():
+            p.copy_(p.to(dtype).float())
+    x = (torch.rand(n, 16, generator=gen) + 0.5).to(dtype).float()
+    params = [p.detach().double().requires_grad_(True) for p in layer.parameters()]
+    xc = x.double().requires_grad_(True)
+    want = O.layer_sum(xc, ei, ea.double(), *params)
+    (want * r.double()).sum().backward()
+    layer = layer.to(dev, dtype)
+
+    def run():
+        for p in layer.parameters():
+            p.grad = None
+        xg = x.to(dev, dtype).requires_grad_(True)
+        out = layer(xg, ei_d, ea.to(dev, dtype))
+        (out.float() * r.to(dev)).sum().backward()
+        return [out.detach().float(), xg.grad.float()] + [p.grad.float().clone() for p in layer.parameters()]
+
+    got = run()
+    assert_close(got[0], want, rtol, what="layer out")
+    if dtype == torch.float32:
+        for g, w in zip(got[1:], [xc.grad] + [p.grad for p in params]):
+            assert_close(g, w, rtol, atol_scale=2.0, what="layer gradient")
+    else:
+        # aggregates of 2,000 positive messages next to rows of 7: in bfloat16 storage the weight gradients of this
+        # construction lose digits to cancellation whatever computes them, so the yardstick is the same layer over
+        # a structure in which every long row is a split row (pieces of 64 edges: no byte count is ever used for it)
+        clear_cache()
+        plain = MPGraph(ei_d, n, chunk=64)
+        assert plain.by_dst.n_big == 0 and plain.by_dst.n_split >= 7
+        register_graph(ei_d, n, plain)
+        for g, w in zip(got[1:], run()[1:]):
+            assert_close(g, w, rtol, atol_scale=2.0, what="layer gradient against the all-split structure")
+    clear_cache()
+
+
 # H <= 128: packed 16-bit mask words; H = 256: 32 lanes per row, one 32-bit word per column group; H = 8: one lane
 @pytest.mark.parametrize("n,e,H,Fe", [(300, 3000, 64, 4), (200, 4000, 128, 4), (100, 700, 24, 2), (150, 2500, 256, 4),
                                       (120, 1500, 8, 1)])
