@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
   // one chunk: start the load of chunk it + D - 1 (into the set chunk it - 1 has just left), multiply chunk it out
   // of LDS buffer it & 1, store the tile at the end of a row step, then move chunk it + 1 from its registers
   // into the other LDS buffer
-  auto body = [&](auto S, int64_t it) {
+  auto body = [&](auto S, int64_t it) __attribute__((always_inline)) {
     constexpr int st = decltype(S)::value;            // == it % D
     using Prev = std::integral_constant<int, (st + D - 1) % D>;
     using Next = std::integral_constant<int, (st + 1) % D>;
@@ -541,6 +541,34 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&p)[3]) {
   for (int i = 0; i < 3; ++i) p[i] = __builtin_bit_cast(bf16x8, make_uint4(lo[i].x, lo[i].y, hi[i].x, hi[i].y));
 }
 
+// Which of the block's 4 x 4 MFMA tiles (32 x 32 each) a wave computes.  Dense: the wave's 64 x 64 quadrant (slot
+// s = 2 i + j is tile (2 (wid >> 1) + i, 2 (wid & 1) + j): fragments are shared inside the quadrant).  When at most
+// half of the 128 x 128 tile lies inside the matrix (narrow weight gradients: 64 hidden channels, 11 or 3 input
+// features) the tiles that do are dealt round-robin over the 4 waves instead, so that no wave multiplies zeros
+// while another one does all the work.
+template <bool SPARSE>
+struct TnSlots {
+  int mt, kt, wid;
+  __device__ __forceinline__ bool on(int s) const { return !SPARSE || s * 4 + wid < mt * kt; }
+  __device__ __forceinline__ int ti(int s) const { return SPARSE ? (on(s) ? (s * 4 + wid) / kt : 0) : 2 * (wid >> 1) + (s >> 1); }
+  __device__ __forceinline__ int tj(int s) const { return SPARSE ? (on(s) ? (s * 4 + wid) % kt : 0) : 2 * (wid & 1) + (s & 1); }
+};
+template <bool SPARSE>
+__device__ __forceinline__ TnSlots<SPARSE> tn_slots(int m_left, int k_left, int wid) {
+  TnSlots<SPARSE> t;
+  t.mt = m_left >= 128 ? 4 : (m_left + 31) / 32;
+  t.kt = k_left >= 128 ? 4 : (k_left + 31) / 32;
+  t.wid = wid;
+  return t;
+}
+// The host picks the SPARSE instantiation when no block of the launch has more than 8 tiles inside the matrix.
+inline bool tn_sparse(int M, int K, int K2) {
+  const int mt = M >= 128 ? 4 : (M + 31) / 32;
+  const int kw = K > K2 ? K : K2;
+  const int kt = kw >= 128 ? 4 : (kw + 31) / 32;
+  return mt * kt <= 8;
+}
+
 // Output tile 128 (m) x 128 (k) per block; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles); 32-row slabs
 // alternate between two LDS buffers with one barrier per slab.
 // SPLIT: the float32 slabs lie in LDS as loaded; a lane reads the 8 contraction values of its output column with
@@ -549,7 +577,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 (&p)[3]) {
 // bfloat16 matrix cores (six piece products, as in k_gemm_nt).
 // Row slabs run through a ring of D register sets (the slab being multiplied is in LDS, the next D - 1 are in
 // flight; every load is issued unconditionally with clamped rows so that the wait counts keep the ring full).
-template <bool ALIGNED, bool SPLIT, bool MASKED>
+template <bool ALIGNED, bool SPLIT, bool MASKED, bool SPARSE>
 __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
   constexpr int D = kTnDepth > 2 && SPLIT && !MASKED ? kTnDepth : 2;
   __shared__ float Gs[2][32][128];
@@ -561,14 +589,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
   const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
   const TnTile xt = tn_tile(a);
   const int m0 = blockIdx.y * 128, k0 = xt.k0;
+  const TnSlots<SPARSE> slots = tn_slots<SPARSE>(a.M - m0, xt.K - k0, wid);
 
-  f32x16 acc[2][2];
+  f32x16 acc0, acc1, acc2, acc3;   // slot s; dense: s = 2 i + j of the wave's quadrant
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
 
   // a thread moves 4 float4 per matrix and slab: rows tid/32 + 8 q, columns 4 (tid % 32) ..
   const int pr = tid >> 5, pc = (tid & 31) * 4;
@@ -617,7 +642,41 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
       *reinterpret_cast<float4*>(&Xs[buf][r][pc]) = select4(xr[st][q], valid4(k0 + pc, xt.K, row_ok));
     }
   };
-  auto multiply = [&](int buf) {
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (SPARSE) {
+      auto one = [&](int sl, f32x16& c) __attribute__((always_inline)) {
+        if (!slots.on(sl)) return;   // uniform over the wave
+        const int cm = 32 * slots.ti(sl) + li, ck = 32 * slots.tj(sl) + li;
+        if constexpr (SPLIT) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            float av[8], bv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              av[j] = Gs[buf][16 * t + 2 * j + lh][cm];
+              bv[j] = Xs[buf][16 * t + 2 * j + lh][ck];
+            }
+            bf16x8 ap[3], bp[3];
+            split8(av, ap);
+            split8(bv, bp);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bp[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[0], c, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int n = 2 * t + lh;
+            c = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[buf][n][cm], Xs[buf][n][ck], c, 0, 0, 0);
+          }
+        }
+      };
+      one(0, acc0); one(1, acc1); one(2, acc2); one(3, acc3);
+      return;
+    }
     if constexpr (SPLIT) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -638,13 +697,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
           split8(bv, bp);
 #pragma unroll
           for (int i = 0; i < 2; ++i) {   // smallest terms first
-            f32x16 c = acc[i][j];
+            f32x16& c = i == 0 ? (j == 0 ? acc0 : acc1) : (j == 0 ? acc2 : acc3);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[2], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[1], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[1], c, 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
           }
         }
       }
@@ -654,10 +713,10 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
         const int n = 2 * t + lh;
         const float a0 = Gs[buf][n][wm + li], a1 = Gs[buf][n][wm + 32 + li];
         const float b0 = Xs[buf][n][wk + li], b1 = Xs[buf][n][wk + 32 + li];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc3, 0, 0, 0);
       }
     }
   };
@@ -665,7 +724,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
   const int64_t step = (int64_t)gridDim.x * 32;
   const int64_t first = (int64_t)blockIdx.x * 32;
   const int64_t total = first < a.N ? (a.N - first + step - 1) / step : 0;   // slabs of this block
-  auto body = [&](auto S, int64_t it) {
+  auto body = [&](auto S, int64_t it) __attribute__((always_inline)) {
     constexpr int st = decltype(S)::value;   // == it % D: the set slab `it` left when it was stashed
     using Next = std::integral_constant<int, (st + 1) % D>;
     const int64_t n0 = first + it * step;
@@ -690,17 +749,16 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
   }
   const int ktot = a.K + a.K2;
   float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
+  auto put = [&](int sl, const f32x16& c) __attribute__((always_inline)) {
+    if (!slots.on(sl)) return;
+    const int cl = k0 + 32 * slots.tj(sl) + li;   // column inside the tile's matrix
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int cl = k0 + wk + j * 32 + li;   // column inside the tile's matrix
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < a.M && cl < xt.K) out[(int64_t)row * ktot + (xt.kout0 - k0) + cl] = acc[i][j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * slots.ti(sl) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < a.M && cl < xt.K) out[(int64_t)row * ktot + (xt.kout0 - k0) + cl] = c[r];
     }
+  };
+  put(0, acc0); put(1, acc1); put(2, acc2); put(3, acc3);
 }
 
 // The split form with hardware-transposed fragment reads (aligned operands).  Slabs of 16 rows are split into
@@ -724,7 +782,7 @@ __device__ __forceinline__ bf16x8 read_tr8(const char* p) {   // rows +0..3 and 
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <bool MASKED>
+template <bool MASKED, bool SPARSE>
 __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
   constexpr int D = MASKED ? 3 : 4;
   __shared__ __attribute__((aligned(16))) char lds[2 * kTrStage];
@@ -735,14 +793,11 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
   const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
   const TnTile xt = tn_tile(a);
   const int m0 = blockIdx.y * 128, k0 = xt.k0;
+  const TnSlots<SPARSE> slots = tn_slots<SPARSE>(a.M - m0, xt.K - k0, wid);
 
-  f32x16 acc[2][2];
+  f32x16 acc0, acc1, acc2, acc3;   // slot s; dense: s = 2 i + j of the wave's quadrant
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; acc3[r] = 0.f; }
 
   // a thread moves 2 float4 per matrix and slab: rows tid/32 + 8 q, columns 4 (tid % 32) ..
   const int pr = tid >> 5, pc = (tid & 31) * 4;
@@ -796,7 +851,28 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
   // this lane's address inside a 32-column tile of a piece plane (see the header comment)
   const int s16 = lane & 15;
   const int frag_off = (8 * lh + (s16 >> 2)) * kTrPitch + (16 * ((lane >> 4) & 1) + 4 * (s16 & 3)) * 2;
-  auto multiply = [&](int buf) {
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (SPARSE) {
+      auto one = [&](int sl, f32x16& c) __attribute__((always_inline)) {
+        if (!slots.on(sl)) return;   // uniform over the wave
+        const char* gb = lds + buf * kTrStage + frag_off + 64 * slots.ti(sl);
+        const char* xb = lds + buf * kTrStage + 3 * kTrPlane + frag_off + 64 * slots.tj(sl);
+        bf16x8 ap[3], bp[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          ap[p] = read_tr8(gb + p * kTrPlane);
+          bp[p] = read_tr8(xb + p * kTrPlane);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[2], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[1], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[0], bp[0], c, 0, 0, 0);
+      };
+      one(0, acc0); one(1, acc1); one(2, acc2); one(3, acc3);
+      return;
+    }
     const char* gbase = lds + buf * kTrStage + frag_off + wm * 2;
     const char* xbase = lds + buf * kTrStage + 3 * kTrPlane + frag_off + wk * 2;
     bf16x8 ap[2][3];
@@ -811,13 +887,13 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
       for (int p = 0; p < 3; ++p) bp[p] = read_tr8(xbase + p * kTrPlane + j * 64);
 #pragma unroll
       for (int i = 0; i < 2; ++i) {   // smallest terms first
-        f32x16 c = acc[i][j];
+        f32x16& c = i == 0 ? (j == 0 ? acc0 : acc1) : (j == 0 ? acc2 : acc3);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[2], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[1], c, 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
       }
     }
   };
@@ -825,7 +901,7 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
   const int64_t step = (int64_t)gridDim.x * kTrRows;
   const int64_t first = (int64_t)blockIdx.x * kTrRows;
   const int64_t total = first < a.N ? (a.N - first + step - 1) / step : 0;   // slabs of this block
-  auto body = [&](auto S, int64_t it) {
+  auto body = [&](auto S, int64_t it) __attribute__((always_inline)) {
     constexpr int st = decltype(S)::value;   // == it % D: the set slab `it` left when it was stashed
     using Next = std::integral_constant<int, (st + 1) % D>;
     const int64_t n0 = first + it * step;
@@ -852,17 +928,16 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
   }
   const int ktot = a.K + a.K2;
   float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
+  auto put = [&](int sl, const f32x16& c) __attribute__((always_inline)) {
+    if (!slots.on(sl)) return;
+    const int cl = k0 + 32 * slots.tj(sl) + li;   // column inside the tile's matrix
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int cl = k0 + wk + j * 32 + li;   // column inside the tile's matrix
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < a.M && cl < xt.K) out[(int64_t)row * ktot + (xt.kout0 - k0) + cl] = acc[i][j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + 32 * slots.ti(sl) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (row < a.M && cl < xt.K) out[(int64_t)row * ktot + (xt.kout0 - k0) + cl] = c[r];
     }
+  };
+  put(0, acc0); put(1, acc1); put(2, acc2); put(3, acc3);
 }
 
 // Two output tiles per block of 8 waves, sharing one operand slab in LDS: PAIR_K = one 128-row tile of G^T
@@ -965,7 +1040,7 @@ __global__ void __launch_bounds__(2 * kBlock) k_gemm_tn_tr2(TnArgs a) {
   const int s16 = lane & 15;
   const int frag_off = (8 * lh + (s16 >> 2)) * kTrPitch + (16 * ((lane >> 4) & 1) + 4 * (s16 & 3)) * 2;
   const int gsel = PAIR_K ? 0 : tw, xsel = PAIR_K ? tw : 0;
-  auto multiply = [&](int buf) {
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
     const char* gbase = lds + buf * kTr2Stage + 3 * gsel * kTrPlane + frag_off + wm * 2;
     const char* xbase = lds + buf * kTr2Stage + 3 * (NG + xsel) * kTrPlane + frag_off + wk * 2;
     bf16x8 ap[2][3];
@@ -994,7 +1069,7 @@ __global__ void __launch_bounds__(2 * kBlock) k_gemm_tn_tr2(TnArgs a) {
   const int64_t step = (int64_t)gridDim.x * kTrRows;
   const int64_t first = (int64_t)blockIdx.x * kTrRows;
   const int64_t total = first < a.N ? (a.N - first + step - 1) / step : 0;   // slabs of this block
-  auto body = [&](auto S, int64_t it) {
+  auto body = [&](auto S, int64_t it) __attribute__((always_inline)) {
     constexpr int st = decltype(S)::value;   // == it % D: the set slab `it` left when it was stashed
     using Next = std::integral_constant<int, (st + 1) % D>;
     const int64_t n0 = first + it * step;
@@ -1259,10 +1334,15 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
     dim3 grid2(slabs, pair_k ? grid.y : (grid.y + 1) / 2, pair_k ? (ztiles + 1) / 2 : ztiles);
     if (pair_k) mask ? launch_tn_pair<true, true>(grid2, a, stream) : launch_tn_pair<false, true>(grid2, a, stream);
     else mask ? launch_tn_pair<true, false>(grid2, a, stream) : launch_tn_pair<false, false>(grid2, a, stream);
-  } else if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true>) : go(k_gemm_tn_tr<false>);
-  else if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true>) : go(k_gemm_tn<true, true, false>);
-  else if (aligned) mask ? go(k_gemm_tn<true, false, true>) : go(k_gemm_tn<true, false, false>);
-  else mask ? go(k_gemm_tn<false, false, true>) : go(k_gemm_tn<false, false, false>);
+  } else if (tn_sparse(M, K, K2)) {   // narrow products: the tiles inside the matrix dealt over all waves
+    if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true, true>) : go(k_gemm_tn_tr<false, true>);
+    else if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true, true>) : go(k_gemm_tn<true, true, false, true>);
+    else if (aligned) mask ? go(k_gemm_tn<true, false, true, true>) : go(k_gemm_tn<true, false, false, true>);
+    else mask ? go(k_gemm_tn<false, false, true, true>) : go(k_gemm_tn<false, false, false, true>);
+  } else if (aligned && gemm_split() && !tn_lds_split()) mask ? go(k_gemm_tn_tr<true, false>) : go(k_gemm_tn_tr<false, false>);
+  else if (aligned && gemm_split()) mask ? go(k_gemm_tn<true, true, true, false>) : go(k_gemm_tn<true, true, false, false>);
+  else if (aligned) mask ? go(k_gemm_tn<true, false, true, false>) : go(k_gemm_tn<true, false, false, false>);
+  else mask ? go(k_gemm_tn<false, false, true, false>) : go(k_gemm_tn<false, false, false, false>);
   MPNN_LAUNCH_CHECK("k_gemm_tn");
   int64_t blocks = ((int64_t)M * ktot + 63) / 64;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
