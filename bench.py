@@ -66,7 +66,7 @@ def layer_bytes_model(n, e, h, fe, s):
     return e * (16 + 4 * h * s + 3 * fe * s) + n * (12 + 7 * h * s)
 
 
-def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0):
+def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0, f=0):
     """Compulsory bytes of one launch of this build's two edge kernels.
 
     aggregate_fwd       per edge: col, B[src] row, edge_attr (+ relu mask words written)
@@ -81,6 +81,12 @@ def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0):
         return e * (4 + h * s + fe * s + 12) + n_rows * (16 + 3 * h * s + 40)
     if kind == "egnn_bwd_src":     # per edge: col_t, A[dst] and G[dst] rows, edge_attr, pos[dst], g pos[dst]
         return e * (4 + 2 * h * s + fe * s + 24) + n_rows * (16 + 2 * h * s + 24)
+    # whole layers in one launch (batches of small graphs): the rows of x in and of y out, the edge list once; the
+    # backward reads x, gy and y, writes gx.  f stands for the input width.
+    if kind == "island_layer_fwd":
+        return e * (4 + fe * s) + n_rows * (4 + (f + h) * s)
+    if kind == "island_layer_bwd":
+        return e * (4 + fe * s) + n_rows * (4 + (2 * f + 2 * h) * s)
     if kind == "aggregate_fwd":
         return e * (4 + h * s + fe * s + 4 * mask_words) + n_rows * (16 + 2 * h * s + h)
     if kind == "aggregate_bwd_src":
@@ -518,12 +524,13 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         rows = {"aggregate_fwd": n_rows_fwd, "aggregate_bwd_src": n_rows_bwd, "egnn_fwd": n_rows_fwd,
-                "egnn_bwd_dst": n_rows_fwd, "egnn_bwd_src": n_rows_bwd}
+                "egnn_bwd_dst": n_rows_fwd, "egnn_bwd_src": n_rows_bwd, "island_layer_fwd": n_rows_fwd,
+                "island_layer_bwd": n_rows_fwd}
         per_kernel = {}
         from mpnn_amd import _lib
         mask_words = _lib.load().mpnn_mask_words(H, _lib.dtype_code(dtype)) if ops.USE_MASKBITS else 0
         for k, tk in kavg.items():
-            b = kernel_bytes(k, rows[k], e_local, H, Fe, s, mask_words)
+            b = kernel_bytes(k, rows[k], e_local, H, Fe, s, mask_words, F_in)
             per_kernel[k] = {"avg_ms": tk * 1e3, "algorithmic_bytes": b, "GBps": b / tk / 1e9}
         dom = max(kavg, key=kavg.get)
         traffic = traffic_src = None

@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 10
+#define MPNN_ABI_VERSION 11
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -470,6 +470,62 @@ int32_t mpnn_adam_step(float* params, const float* grads, float* exp_avg, float*
 int64_t mpnn_knn_workspace_floats(int32_t num_clouds, int32_t points, int32_t k);
 int32_t mpnn_knn_graph(const float* pos, int32_t num_clouds, int32_t points, int32_t k, int64_t* edge_index,
                        float* edge_attr, float* workspace, mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Whole layers for batches of small graphs, one wavefront per graph.
+ *
+ * The mini-batches of the molecule workloads (DataLoader batches of data/dataset.py:94-96, consumed by
+ * training/train.py:94-98) are disjoint unions of graphs of a few dozen nodes.  An ISLAND is a run of consecutive
+ * node ids that no edge leaves; a layer (models/layers.py:91-140, both forms after the column split of
+ * `linear.weight`) never moves data between islands, so one wavefront can run the whole layer for one island out
+ * of LDS: projection, messages, sum per destination, update - and in the backward every gradient - in ONE launch
+ * each way (plus a fixed-order sum of per-block weight-gradient partials), instead of a dozen launches whose
+ * working sets are a few kilobytes.  Results are deterministic; they agree with the general path to rounding.
+ *
+ * mpnn_islands_build finds the islands of a destination-sorted CSR (mpnn_csr_build output in row-id order):
+ *   island_ptr [num_nodes + 1]: island i = nodes island_ptr[i] .. island_ptr[i+1]-1 (ascending, island_ptr[0] = 0)
+ *   meta [4]: { number of islands, nodes of the largest island, edges of the largest island, 0 }
+ *   workspace: mpnn_islands_workspace_bytes(num_nodes) bytes.
+ * A batch assembled by mpnn_collate can use its graph offsets (slot table row 0) as island_ptr directly.
+ *
+ * mpnn_island_layer_fwd / _bwd run MPNNLayerSum.forward and its autograd backward (pos == NULL), or the EGNN
+ * layer (messages as above plus pos'[n] = pos[n] + sum_{e -> n} (pos[n] - pos[src]) * (w_pos . m_e)) when pos is
+ * given.  Limits: H = 64 or 128, 1 <= Fe <= 8, every island at most `rows` nodes, and a tile of `rows` nodes
+ * must fit the LDS (mpnn_island_layer_waves(...) >= 1).  Rows from island_ptr[n_islands] up to num_nodes must
+ * have no edges (the padding rows of a fixed-capacity batch); they are processed `rows` at a time by
+ * `tail_units` further wavefronts (tail_units * rows >= the number of such rows; 0 when there are none).
+ * The backward recomputes the forward intermediates from x, so nothing but y needs to be kept.
+ *   rows       tile height: a multiple of 8, >= the largest island
+ *   x [N, F] (ldx), ea [E, Fe] in CSR order, w_nodes [2H, F], w_edge [H, Fe], w_out [H, F + H], w_pos [H]: `dtype`
+ *   pos, pos_out, gpos_out (gradient arriving at pos'), gpos (gradient of pos): float [N, 3]
+ *   y [N, H] (ldy): output of the forward, input of the backward
+ *   gy [N, H] (ldgy); gx [N, F] (ldgx) or NULL when the gradient of x is not wanted
+ *   g_wn [2H, F], g_we [H, Fe], g_wout [H, F + H], g_wpos [H]: `dtype`, contiguous, each may be NULL
+ *   partial    mpnn_island_layer_partial_floats(...) floats of scratch (backward)
+ *   gx_part    float [N, F] scratch (backward, only when gx is given)
+ * ------------------------------------------------------------------------- */
+typedef struct mpnn_island_layer {
+  const int32_t* rowptr; const int32_t* col; const int32_t* island_ptr;
+  int32_t n_islands; int32_t tail_units; int32_t rows; int64_t num_nodes;
+  const void* x; int64_t ldx;
+  const void* ea; const void* w_nodes; const void* w_edge; const void* w_out;
+  const float* pos; const void* w_pos;
+  int32_t F; int32_t H; int32_t Fe; int32_t dtype;
+  void* y; int64_t ldy; float* pos_out;
+  const void* gy; int64_t ldgy; const float* gpos_out;
+  void* gx; int64_t ldgx; float* gpos;
+  void* g_wn; void* g_we; void* g_wout; void* g_wpos;
+  float* partial; float* gx_part;
+} mpnn_island_layer;
+int64_t mpnn_islands_workspace_bytes(int64_t num_nodes);
+int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t* island_ptr,
+                           int32_t* meta, void* workspace, int64_t workspace_bytes, mpnn_stream_t stream);
+/* wavefronts (= islands) per block that fit the LDS for this shape; 0 = the shape is not supported */
+int32_t mpnn_island_layer_waves(int32_t rows, int32_t F, int32_t H, int32_t egnn, int32_t backward);
+int64_t mpnn_island_layer_partial_floats(int32_t n_islands, int32_t tail_units, int32_t rows, int32_t F, int32_t H,
+                                         int32_t Fe, int32_t egnn);
+int32_t mpnn_island_layer_fwd(const mpnn_island_layer* desc, mpnn_stream_t stream);
+int32_t mpnn_island_layer_bwd(const mpnn_island_layer* desc, mpnn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 MPNN_F32 = 0
 MPNN_BF16 = 1
 MPNN_U8 = 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -39,8 +39,31 @@ class CollateDesc(ctypes.Structure):
     ]
 
 
+class IslandLayerDesc(ctypes.Structure):
+    """struct mpnn_island_layer of include/mpnn_amd.h (field for field)."""
+    _fields_ = [
+        ("rowptr", c_void_p), ("col", c_void_p), ("island_ptr", c_void_p),
+        ("n_islands", c_int32), ("tail_units", c_int32), ("rows", c_int32), ("num_nodes", c_int64),
+        ("x", c_void_p), ("ldx", c_int64),
+        ("ea", c_void_p), ("w_nodes", c_void_p), ("w_edge", c_void_p), ("w_out", c_void_p),
+        ("pos", c_void_p), ("w_pos", c_void_p),
+        ("F", c_int32), ("H", c_int32), ("Fe", c_int32), ("dtype", c_int32),
+        ("y", c_void_p), ("ldy", c_int64), ("pos_out", c_void_p),
+        ("gy", c_void_p), ("ldgy", c_int64), ("gpos_out", c_void_p),
+        ("gx", c_void_p), ("ldgx", c_int64), ("gpos", c_void_p),
+        ("g_wn", c_void_p), ("g_we", c_void_p), ("g_wout", c_void_p), ("g_wpos", c_void_p),
+        ("partial", c_void_p), ("gx_part", c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/mpnn_amd.h one to one.
 SIGNATURES = {
+    "mpnn_islands_workspace_bytes": (c_int64, [c_int64]),
+    "mpnn_islands_build": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpnn_island_layer_waves": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mpnn_island_layer_partial_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mpnn_island_layer_fwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_void_p]),
+    "mpnn_island_layer_bwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_void_p]),
     "mpnn_collate": (c_int32, [ctypes.POINTER(CollateDesc), c_void_p]),
     "mpnn_knn_workspace_floats": (c_int64, [c_int32, c_int32, c_int32]),
     "mpnn_knn_graph": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -19,7 +19,7 @@ from typing import Tuple
 import torch
 from torch import Tensor
 
-from . import _lib, layer_fn, ops
+from . import _lib, islands, layer_fn, ops
 from .graph import graph_for
 
 
@@ -65,8 +65,9 @@ def layer_bwd(gy: Tensor, x: Tensor, edge_index: Tensor, edge_attr: Tensor, ab: 
               cnt_big: Tensor, maskbits: Tensor, y: Tensor, w_nodes: Tensor, w_edge: Tensor, w_out: Tensor, need_x: bool, need_wn: bool,
               need_we: bool, need_wout: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     graph = graph_for(edge_index, x.size(0))
-    ea_t = graph.sorted_edge_attr(edge_attr, x.dtype)[1]
     x = x if x.is_contiguous() and x.data_ptr() % 16 == 0 else x.clone(memory_format=torch.contiguous_format)
+    one_launch = islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), False) is not None
+    ea_t = graph.sorted_edge_attr(edge_attr, x.dtype)[0 if one_launch else 1]   # the layout layer_fwd's path reads
     bits = maskbits if maskbits.size(1) > 0 else None
     counts = (cnt, cnt_big if cnt_big.size(0) > 0 else None)
     grads = layer_fn.backward_impl(gy, x, ab, aggr, counts, bits, y, ea_t, w_nodes, w_edge, w_out, graph,

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import CHUNK, CSR, MPGraph, forget_graph, register_graph
+from .graph import CHUNK, CSR, Islands, MPGraph, forget_graph, register_graph
 from .ops import register_pool
 
 
@@ -106,6 +106,7 @@ class GraphStore:
         # the fused path writes one work item per row, which is the general builder's result only while no row
         # is long enough to be split
         self.fused = self.max_degree <= CHUNK
+        self.max_graph_nodes = int((self.node_ptr[1:] - self.node_ptr[:-1]).max()) if self.num_graphs else 0
         self._iota = torch.arange(0, dtype=torch.int32, device=dev)
 
     @classmethod
@@ -209,7 +210,10 @@ class GraphStore:
                 c.items, c.split = parts["items_" + sfx], None
                 c.n_items, c.n_parts, c.n_split = n_out, 0, 0
                 views.append(c)
-            res._graph = MPGraph.from_parts(views[0], views[1], parts["tpos"])
+            # the graphs of the batch are its islands (row 0 of the slot table = their first nodes); the rows of a
+            # padded batch past the real nodes have no edges
+            isl = Islands(parts["slots"][0], b, self.max_graph_nodes, tail_rows=n_out if capacity is not None else 0)
+            res._graph = MPGraph.from_parts(views[0], views[1], parts["tpos"], isl)
         if self._iota.numel() < n_out:
             self._iota = torch.arange(max(n_out, 2 * self._iota.numel()), **i32)
         self._register(res, n)

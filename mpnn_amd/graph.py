@@ -8,6 +8,7 @@ pay per batch.
 from __future__ import annotations
 
 import collections
+import os
 
 import torch
 
@@ -24,6 +25,24 @@ BYTE_COUNT_MAX = 255    # a target row of at most this many edges has exact one-
 # Edge lists of at least this many edges get their sorted views laid out in work-item order by graph_for()
 # (see MPGraph, ``row_order``).
 ITEM_ORDER_MIN_EDGES = 1 << 22
+
+
+# Graphs of at most this many nodes are searched for islands when their structure is built (one more launch of
+# the build, its result read back with the item counts); see Islands.  MPNN_AMD_ISLANDS=1 switches the search and
+# with it the one-launch layers on.
+ISLAND_SEARCH_MAX_NODES = 1 << 16
+ISLANDS_ENABLED = os.environ.get("MPNN_AMD_ISLANDS", "0") == "1"
+
+
+class Islands:
+    """Runs of consecutive nodes that no edge leaves (the graphs of a collated batch): island i = nodes
+    ptr[i] .. ptr[i+1]-1.  ``max_nodes`` bounds every island; rows from ptr[count] up to the graph's node count
+    (padding of a fixed-capacity batch) have no edges and are processed ``tail_units`` tiles at most."""
+
+    __slots__ = ("ptr", "count", "max_nodes", "max_edges", "tail_rows")
+
+    def __init__(self, ptr, count, max_nodes, max_edges=0, tail_rows=0):
+        self.ptr, self.count, self.max_nodes, self.max_edges, self.tail_rows = ptr, count, max_nodes, max_edges, tail_rows
 
 
 def default_chunk(num_edges: int) -> int:
@@ -128,9 +147,15 @@ def _rows_into_item_order(csr: CSR, status: torch.Tensor, chunk: int) -> None:
     csr.rowptr, csr.col, csr.eid, csr.order = rowptr, col, eid, order
 
 
-def _finish(csrs, pending) -> None:
-    """One host read for all CSRs built together: item counts, overflow flag, range-check flag."""
-    host = torch.stack(pending).tolist()
+def _finish(csrs, pending, extra=None):
+    """One host read for all CSRs built together: item counts, overflow flag, range-check flag.  ``extra``: one more
+    6-entry device record to bring along; its host copy is returned."""
+    host = torch.stack(pending + ([extra] if extra is not None else [])).tolist()
+    _apply(csrs, host)
+    return host[len(csrs)] if extra is not None else None
+
+
+def _apply(csrs, host) -> None:
     for csr, h in zip(csrs, host):
         if h[4] != 0:
             raise IndexError(f"edge_index holds node ids outside [0, {csr.num_rows}) x [0, {csr.num_cols})")
@@ -188,7 +213,11 @@ class MPGraph:
         by_items = row_order == "items" and self.num_edges > 0
         self.by_dst, p1 = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts, by_items)
         self.by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, by_items)
-        _finish([self.by_dst, self.by_src], [p1, p2])
+        self.islands = None
+        found = self._search_islands() if (not by_items and self.num_dst == self.num_src) else None
+        meta = _finish([self.by_dst, self.by_src], [p1, p2], found[1] if found else None)
+        if found and meta[0] > 0:
+            self.islands = Islands(found[0], meta[0], meta[1], meta[2])
         if by_items:
             _rows_to_ids(self.by_dst)
             _rows_to_ids(self.by_src)
@@ -197,8 +226,24 @@ class MPGraph:
         self._scratch = {}
         self._tpos = None
 
+    def _search_islands(self):
+        """Launches the island search over the destination view; (island_ptr, 6-entry result record) or None."""
+        n = self.num_dst
+        if not ISLANDS_ENABLED or n == 0 or n > ISLAND_SEARCH_MAX_NODES:
+            return None
+        lib = _lib.load()
+        dev = self.by_dst.rowptr.device
+        ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        meta = torch.zeros(6, dtype=torch.int32, device=dev)
+        ws = torch.empty(lib.mpnn_islands_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        _lib.check(lib.mpnn_islands_build(_lib.ptr(self.by_dst.rowptr), _lib.ptr(self.by_dst.col), n, _lib.ptr(ptr),
+                                          _lib.ptr(meta), _lib.ptr(ws), ws.numel(), _lib.stream_handle(dev)),
+                   "mpnn_islands_build")
+        return ptr, meta
+
     @classmethod
-    def from_parts(cls, by_dst: CSR, by_src: CSR, tpos: torch.Tensor | None = None) -> "MPGraph":
+    def from_parts(cls, by_dst: CSR, by_src: CSR, tpos: torch.Tensor | None = None,
+                   islands: Islands | None = None) -> "MPGraph":
         """Wraps index structures that were produced elsewhere (the batch assembler writes them directly)."""
         g = cls.__new__(cls)
         g.num_dst, g.num_src, g.num_edges = by_dst.num_rows, by_src.num_rows, by_dst.num_edges
@@ -207,6 +252,7 @@ class MPGraph:
         g._ea_sorted = None
         g._scratch = {}
         g._tpos = tpos
+        g.islands = islands if ISLANDS_ENABLED else None
         return g
 
     def seed_edge_attr(self, edge_attr: torch.Tensor, ea_dst: torch.Tensor, ea_src: torch.Tensor) -> None:

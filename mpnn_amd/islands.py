@@ -1,0 +1,131 @@
+"""One-launch layers for batches of small graphs (the library's island kernels).
+
+A mini-batch of molecules (data/dataset.py:94-96) is a disjoint union of graphs of a few dozen nodes, and a layer
+(models/layers.py:91-140) never moves data between them.  When the graph structure knows its islands (graph.Islands)
+and they are small enough, the layer runs as mpnn_island_layer_fwd / mpnn_island_layer_bwd: one wavefront per
+island, every intermediate in LDS, one launch forward and two backward, instead of the general sequence of GEMM and
+edge-pass launches whose working sets would be a few kilobytes each.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+from .graph import MPGraph
+from .ops import _Timed
+
+ROWS_MAX = 64          # tallest tile the kernels are given (nodes of the largest island, rounded up to 8)
+# Beyond this many islands the batch is large enough for the general path's matrix-core GEMMs to win.
+COUNT_MAX = int(os.environ.get("MPNN_AMD_ISLANDS_MAX", "4096"))
+
+
+class Plan:
+    __slots__ = ("rows", "tail_units", "egnn")
+
+    def __init__(self, rows, tail_units, egnn):
+        self.rows, self.tail_units, self.egnn = rows, tail_units, egnn
+
+
+def plan_for(graph: MPGraph, f: int, h: int, fe: int, egnn: bool) -> Plan | None:
+    """The tile shape for this layer on this graph, or None when the island kernels do not apply (no islands known,
+    islands too large or too many, widths outside the kernels' range)."""
+    isl = getattr(graph, "islands", None)
+    if isl is None or isl.count == 0 or isl.count > COUNT_MAX:
+        return None
+    if h not in (64, 128) or not 1 <= fe <= 8 or f < 1:
+        return None
+    rows = max(8, (isl.max_nodes + 7) // 8 * 8)
+    if rows > ROWS_MAX:
+        return None
+    lib = _lib.load()
+    if lib.mpnn_island_layer_waves(rows, f, h, int(egnn), 1) < 1:
+        return None
+    tail_units = (isl.tail_rows + rows - 1) // rows
+    return Plan(rows, tail_units, egnn)
+
+
+def _desc(plan: Plan, graph: MPGraph, x, ea_s, w_nodes, w_edge, w_out, y, pos=None, w_pos=None) -> _lib.IslandLayerDesc:
+    isl, csr = graph.islands, graph.by_dst
+    d = _lib.IslandLayerDesc()
+    P = _lib.ptr
+    d.rowptr, d.col, d.island_ptr = P(csr.rowptr), P(csr.col), P(isl.ptr)
+    d.n_islands, d.tail_units, d.rows, d.num_nodes = isl.count, plan.tail_units, plan.rows, x.size(0)
+    d.x, d.ldx = P(x), x.stride(0)
+    d.ea, d.w_nodes, d.w_edge, d.w_out = P(ea_s), P(w_nodes), P(w_edge), P(w_out)
+    d.pos, d.w_pos = P(pos), P(w_pos)
+    d.F, d.H, d.Fe, d.dtype = x.size(1), w_out.size(0), ea_s.size(1), _lib.dtype_code(x.dtype)
+    d.y, d.ldy = P(y), y.stride(0)
+    return d
+
+
+def _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
+    n, f = x.shape
+    h = w_out.size(0)
+    if n != graph.num_dst:
+        raise ValueError(f"x has {n} rows, the graph {graph.num_dst} nodes")
+    if w_nodes.shape != (2 * h, f) or w_out.shape != (h, f + h) or w_edge.shape != (h, edge_attr.size(1)):
+        raise ValueError(f"weights {tuple(w_nodes.shape)}, {tuple(w_edge.shape)}, {tuple(w_out.shape)} do not fit "
+                         f"x [{n}, {f}] and edge_attr [{edge_attr.size(0)}, {edge_attr.size(1)}]")
+    if edge_attr.requires_grad:
+        raise NotImplementedError("gradient with respect to edge_attr is not implemented by the HIP engine")
+    x = x if x.is_contiguous() else x.contiguous()
+    ea_s = graph.sorted_edge_attr(edge_attr, x.dtype)[0]
+    return x, ea_s, w_nodes.contiguous(), w_edge.contiguous(), w_out.contiguous()
+
+
+def forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, pos=None, w_pos=None):
+    """y (and pos' for the EGNN form) of one layer.  Returns (y, pos_out | None, saved) where ``saved`` are the
+    contiguous tensors the backward needs."""
+    x, ea_s, w_nodes, w_edge, w_out = _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph)
+    lib = _lib.load()
+    y = torch.empty((x.size(0), w_out.size(0)), dtype=x.dtype, device=x.device)
+    pos_out = None
+    if plan.egnn:
+        pos = pos.contiguous()
+        w_pos = w_pos.contiguous()
+        pos_out = torch.empty_like(pos)
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
+    d.pos_out = _lib.ptr(pos_out)
+    with _Timed("island_layer_fwd", x.device):
+        _lib.check(lib.mpnn_island_layer_fwd(ctypes.byref(d), _lib.stream_handle(x.device)), "mpnn_island_layer_fwd")
+    return y, pos_out, (x, ea_s, w_nodes, w_edge, w_out, pos, w_pos)
+
+
+def backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None):
+    """Gradients of one layer.  ``needs`` = (x, w_nodes, w_edge, w_out) wanted; returns (gx, g_wn, g_we, g_wout,
+    gpos, g_wpos), None where not wanted (gpos / g_wpos only for the EGNN form)."""
+    x, ea_s, w_nodes, w_edge, w_out, pos, w_pos = saved
+    need_x, need_wn, need_we, need_wout = needs
+    lib = _lib.load()
+    dev, dt = x.device, x.dtype
+    n, f = x.shape
+    h = w_out.size(0)
+    gy = gy if gy.is_contiguous() else gy.contiguous()
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
+    d.gy, d.ldgy = _lib.ptr(gy), gy.stride(0)
+    gx = torch.empty((n, f), dtype=dt, device=dev) if need_x else None
+    g_wn = torch.empty_like(w_nodes) if need_wn else None
+    g_we = torch.empty_like(w_edge) if need_we else None
+    g_wout = torch.empty_like(w_out) if need_wout else None
+    gpos = g_wpos = None
+    if plan.egnn:
+        gpos_out = gpos_out.contiguous().float()
+        gpos = torch.empty_like(pos)
+        g_wpos = torch.empty_like(w_pos)
+        d.gpos_out, d.gpos, d.g_wpos = _lib.ptr(gpos_out), _lib.ptr(gpos), _lib.ptr(g_wpos)
+    d.gx, d.ldgx = _lib.ptr(gx), (gx.stride(0) if gx is not None else 0)
+    d.g_wn, d.g_we, d.g_wout = _lib.ptr(g_wn), _lib.ptr(g_we), _lib.ptr(g_wout)
+    isl = graph.islands
+    floats = lib.mpnn_island_layer_partial_floats(isl.count, plan.tail_units, plan.rows, f, h, ea_s.size(1), int(plan.egnn))
+    if floats < 0:
+        raise _lib.MpnnError("mpnn_island_layer_partial_floats rejected the layer's shape")
+    partial = graph.scratch("island_partial", (max(floats, 1),), torch.float32, dev)
+    d.partial = _lib.ptr(partial)
+    if need_x:
+        d.gx_part = _lib.ptr(graph.scratch("island_gx", (n, f), torch.float32, dev))
+    with _Timed("island_layer_bwd", dev):
+        _lib.check(lib.mpnn_island_layer_bwd(ctypes.byref(d), _lib.stream_handle(dev)), "mpnn_island_layer_bwd")
+    return gx, g_wn, g_we, g_wout, gpos, g_wpos

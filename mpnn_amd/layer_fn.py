@@ -15,19 +15,28 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
+from . import islands, ops
 from .dense import gemm_nt, gemm_nt_bf16, gemm_tn, gemm_tn_bf16
 from .graph import MPGraph
 
 
 def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: bool):
-    """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea_t); cnt = (byte counts, exact
+    """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea); cnt = (byte counts, exact
     counts of the long rows or None) and maskbits are None when ``want`` (a backward will follow) is false, maskbits
-    also when no mask layout exists."""
+    also when no mask layout exists.  ``ea`` is the sorted layout of edge_attr the backward reads: transpose order
+    on the general path, destination order when the graph's islands let the layer run as one launch."""
     bf = x.dtype == torch.bfloat16
     x = x if x.is_contiguous() else x.contiguous()
     f = x.size(1)
     h = w_out.size(0)
+    plan = islands.plan_for(graph, f, h, edge_attr.size(1), False)
+    if plan is not None:
+        # one launch for the whole layer; its backward recomputes the intermediates, so the slots that carry them
+        # on the general path hold unwritten tensors of the same shapes
+        y, _, saved = islands.forward(plan, graph, x, edge_attr, w_nodes, w_edge, w_out)
+        n = x.size(0)
+        cnt = (torch.empty((n, h), dtype=torch.uint8, device=x.device), None) if want else None
+        return y, x.new_empty((n, 2 * h)), x.new_empty((n, h)), cnt, None, saved[1]
     ab = gemm_nt_bf16(x, w_nodes.contiguous()) if bf else gemm_nt(x, w_nodes)
     a, b = ab[:, :h], ab[:, h:]
     ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
@@ -43,11 +52,15 @@ def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: boo
 
 def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_out, graph: MPGraph, needs):
     """The backward sequence.  ``needs`` = (x, w_nodes, w_edge, w_out) gradients wanted; returns them in that order
-    (None where not wanted)."""
+    (None where not wanted).  ``ea_t`` is the ``ea`` forward_impl returned."""
     need_x, need_wn, need_we, need_wout = needs
     bf = x.dtype == torch.bfloat16
     f = x.size(1)
     h = w_out.size(0)
+    plan = islands.plan_for(graph, f, h, w_edge.size(1), False)
+    if plan is not None:   # the choice forward_impl made: it depends on the graph and the shapes only
+        saved = (x, ea_t, w_nodes.contiguous(), w_edge.contiguous(), w_out.contiguous(), None, None)
+        return islands.backward(plan, graph, gy, y, saved, needs)[:4]
     w_edge = w_edge.contiguous()
     gy = gy if gy.is_contiguous() else gy.contiguous()
     if gy.data_ptr() % 16:
@@ -125,6 +138,13 @@ class _EgnnLayerFn(torch.autograd.Function):
         nt = gemm_nt_bf16 if bf else gemm_nt
         x = x if x.is_contiguous() else x.contiguous()
         f, h = x.size(1), w_out.size(0)
+        ctx.plan = islands.plan_for(graph, f, h, edge_attr.size(1), True)
+        ctx.w_pos_shape = w_pos.shape
+        if ctx.plan is not None:   # the whole layer in one launch; the backward recomputes the intermediates
+            y, pos_out, saved = islands.forward(ctx.plan, graph, x, edge_attr, w_nodes, w_edge, w_out, pos, w_pos.reshape(-1))
+            ctx.save_for_backward(y, *saved)
+            ctx.graph = graph
+            return y, pos_out
         ab = nt(x, w_nodes.contiguous())
         a, b = ab[:, :h], ab[:, h:]
         pos_c, wp, we = pos.contiguous(), w_pos.contiguous(), w_edge.contiguous()
@@ -140,6 +160,13 @@ class _EgnnLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, gp):
+        if ctx.plan is not None:
+            y, *saved = ctx.saved_tensors
+            needs = tuple(ctx.needs_input_grad[i] for i in (0, 3, 4, 5))
+            gx, g_wn, g_we, g_wout, g_pos, g_wp = islands.backward(ctx.plan, ctx.graph, gy, y, tuple(saved), needs, gp)
+            w_pos_shape = ctx.w_pos_shape
+            return (gx, g_pos if ctx.needs_input_grad[1] else None, None, g_wn, g_we, g_wout,
+                    g_wp.reshape(w_pos_shape) if ctx.needs_input_grad[6] else None, None)
         x, ab, aggr, y, pos, ea_s, ea_t, w_nodes, we, w_out, wp = ctx.saved_tensors
         bf = x.dtype == torch.bfloat16
         nt, tn = (gemm_nt_bf16, gemm_tn_bf16) if bf else (gemm_nt, gemm_tn)
@@ -214,8 +241,8 @@ def _check_dtypes(x, edge_attr, *weights):
 @torch.compiler.disable
 def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph) -> torch.Tensor:
     _check_dtypes(x, edge_attr, w_nodes, w_edge, w_out)
-    if x.dtype == torch.bfloat16:
-        x, w_nodes, w_out = _pad_features(x, w_nodes, w_out)
+    if x.dtype == torch.bfloat16 and islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), False) is None:
+        x, w_nodes, w_out = _pad_features(x, w_nodes, w_out)     # (the one-launch kernels take any input width)
     return _LayerFn.apply(x, edge_attr, w_nodes, w_edge, w_out, graph)
 
 
@@ -223,6 +250,6 @@ def layer_forward(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph) -> torch
 def egnn_layer_forward(x, pos, edge_attr, w_nodes, w_edge, w_out, w_pos, graph: MPGraph):
     """(y [N, H], pos' [N, 3]) of one EGNN layer; pos and its gradient are float32 whatever the feature dtype."""
     _check_dtypes(x, edge_attr, w_nodes, w_edge, w_out, w_pos)
-    if x.dtype == torch.bfloat16:
+    if x.dtype == torch.bfloat16 and islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), True) is None:
         x, w_nodes, w_out = _pad_features(x, w_nodes, w_out)
     return _EgnnLayerFn.apply(x, pos.float(), edge_attr, w_nodes, w_edge, w_out, w_pos, graph)

@@ -130,8 +130,15 @@ def test_egnn_model_logits_and_every_gradient(workload, dtype):
     kink = max(KINK[dtype], 5e-4)
     assert_close(xg.grad.float(), xc.grad, rtol * loose, atol_scale=4.0, what="grad x", kink_frac=kink)
     assert_close(pg.grad, pc.grad, rtol * loose, atol_scale=4.0, what="grad pos", kink_frac=kink)
+    # A flipped decision of column c in the second layer moves rows c and c + H of that layer's projection gradient
+    # and row c of its edge-weight gradient by one message's worth, and a little of every row of the first layer's
+    # gradients: a fraction of a SMALL tensor that no per-entry share describes.  (The QM9 batch has a second-layer
+    # pre-activation of 1.7e-8 in float64 against a typical 0.26 - tools/egnn_flip_debug.py prints it - so which
+    # side a correct float32 evaluation lands on is a matter of its summation order.)  Such entries may be up to 5 %
+    # of a weight gradient but must stay within 2e-3 of its scale; everything else meets the bar.
     for k, p in model.named_parameters():
-        assert_close(p.grad.float(), params[k].grad, rtol * loose, atol_scale=4.0, what=f"grad {k}", kink_frac=kink)
+        assert_close(p.grad.float(), params[k].grad, rtol * loose, atol_scale=4.0, what=f"grad {k}",
+                     kink_frac=max(kink, 0.05), kink_max=2e-3 if dtype == torch.float32 else None)
 
 
 def test_bf16_layers_with_input_widths_that_are_not_multiples_of_8_stay_on_the_library_gemms():
