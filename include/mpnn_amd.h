@@ -490,12 +490,13 @@ int32_t mpnn_knn_graph(const float* pos, int32_t num_clouds, int32_t points, int
  *
  * mpnn_island_layer_fwd / _bwd run MPNNLayerSum.forward and its autograd backward (pos == NULL), or the EGNN
  * layer (messages as above plus pos'[n] = pos[n] + sum_{e -> n} (pos[n] - pos[src]) * (w_pos . m_e)) when pos is
- * given.  Limits: H = 64 or 128, 1 <= Fe <= 8, every island at most `rows` nodes, and a tile of `rows` nodes
- * must fit the LDS (mpnn_island_layer_waves(...) >= 1).  Rows from island_ptr[n_islands] up to num_nodes must
- * have no edges (the padding rows of a fixed-capacity batch); they are processed `rows` at a time by
- * `tail_units` further wavefronts (tail_units * rows >= the number of such rows; 0 when there are none).
+ * given.  Limits: H = 64 or 128, 1 <= Fe <= 8, every island at most 32 nodes (the height of a matrix-core tile;
+ * `rows` must be 32), and a tile must fit the LDS (mpnn_island_layer_waves(...) >= 1).  Rows from
+ * island_ptr[n_islands] up to num_nodes must have no edges (the padding rows of a fixed-capacity batch); they are
+ * processed 32 at a time by `tail_units` further wavefronts (tail_units * 32 >= the number of such rows; 0 when
+ * there are none).
  * The backward recomputes the forward intermediates from x, so nothing but y needs to be kept.
- *   rows       tile height: a multiple of 8, >= the largest island
+ *   rows       32
  *   x [N, F] (ldx), ea [E, Fe] in CSR order, w_nodes [2H, F], w_edge [H, Fe], w_out [H, F + H], w_pos [H]: `dtype`
  *   pos, pos_out, gpos_out (gradient arriving at pos'), gpos (gradient of pos): float [N, 3]
  *   y [N, H] (ldy): output of the forward, input of the backward
@@ -521,9 +522,9 @@ int64_t mpnn_islands_workspace_bytes(int64_t num_nodes);
 int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t* island_ptr,
                            int32_t* meta, void* workspace, int64_t workspace_bytes, mpnn_stream_t stream);
 /* wavefronts (= islands) per block that fit the LDS for this shape; 0 = the shape is not supported */
-int32_t mpnn_island_layer_waves(int32_t rows, int32_t F, int32_t H, int32_t egnn, int32_t backward);
-int64_t mpnn_island_layer_partial_floats(int32_t n_islands, int32_t tail_units, int32_t rows, int32_t F, int32_t H,
-                                         int32_t Fe, int32_t egnn);
+int32_t mpnn_island_layer_waves(int32_t F, int32_t H, int32_t Fe, int32_t egnn, int32_t backward);
+int64_t mpnn_island_layer_partial_floats(int32_t n_islands, int32_t tail_units, int32_t F, int32_t H, int32_t Fe,
+                                         int32_t egnn);
 int32_t mpnn_island_layer_fwd(const mpnn_island_layer* desc, mpnn_stream_t stream);
 int32_t mpnn_island_layer_bwd(const mpnn_island_layer* desc, mpnn_stream_t stream);
 

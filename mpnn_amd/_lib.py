@@ -61,7 +61,7 @@ SIGNATURES = {
     "mpnn_islands_workspace_bytes": (c_int64, [c_int64]),
     "mpnn_islands_build": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mpnn_island_layer_waves": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
-    "mpnn_island_layer_partial_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mpnn_island_layer_partial_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "mpnn_island_layer_fwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_void_p]),
     "mpnn_island_layer_bwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_void_p]),
     "mpnn_collate": (c_int32, [ctypes.POINTER(CollateDesc), c_void_p]),

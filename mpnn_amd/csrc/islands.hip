@@ -30,76 +30,93 @@ constexpr int kScanBlock = 1024;
 // ---------------------------------------------------------------------------------------------------------------
 // structure: the islands of a destination-sorted CSR
 // ---------------------------------------------------------------------------------------------------------------
+// Inclusive scan over the block's 1024 threads: a shuffle scan inside every wave, then the 16 wave totals.
 template <typename Op>
-__device__ __forceinline__ int block_scan_inclusive(int v, int* sm, Op op) {   // sm: 2 * kScanBlock ints
-  const int t = threadIdx.x;
-  int cur = 0;
-  sm[t] = v;
-  __syncthreads();
-  for (int off = 1; off < kScanBlock; off <<= 1) {
-    int x = sm[cur * kScanBlock + t];
-    if (t >= off) x = op(sm[cur * kScanBlock + t - off], x);
-    cur ^= 1;
-    sm[cur * kScanBlock + t] = x;
-    __syncthreads();
+__device__ __forceinline__ int block_scan_inclusive(int v, int* sm, Op op) {   // sm: 16 ints
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(v, off, 64);
+    if (lane >= off) v = op(o, v);
   }
-  const int r = sm[cur * kScanBlock + t];
+  if (lane == 63) sm[wv] = v;
   __syncthreads();
-  return r;
+  for (int i = 0; i < wv; ++i) v = op(sm[wv - 1 - i], v);   // (op is commutative and associative: min, max, +)
+  __syncthreads();
+  return v;
 }
 
-// A cut after node r (between r and r + 1) separates two islands iff no edge spans it: no row <= r has a source
-// > r (prefix maximum of the rows' largest node id) and no row > r has a source <= r (suffix minimum of the rows'
-// smallest node id).  One block: the scans run over chunks of 1024 rows with a carry.
-__global__ void __launch_bounds__(kScanBlock) k_islands_build(const int32_t* __restrict__ rowptr,
-                                                              const int32_t* __restrict__ col, int n,
-                                                              int32_t* __restrict__ island_ptr, int32_t* __restrict__ meta,
-                                                              int32_t* __restrict__ sufmin) {
-  __shared__ int sm[2 * kScanBlock];
-  __shared__ int carry, count, max_nodes, max_edges;
+// lo[r] / hi[r] = smallest / largest node id among row r and the sources of its edges.
+__global__ void __launch_bounds__(256) k_island_bounds(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                       int n, int32_t* __restrict__ lo, int32_t* __restrict__ hi) {
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    int a = r, b = r;
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const int c = col[e];
+      a = c < a ? c : a;
+      b = c > b ? c : b;
+    }
+    lo[r] = a;
+    hi[r] = b;
+  }
+}
+
+// A cut after node r (between r and r + 1) separates two islands iff no edge spans it: no row <= r reaches a
+// node > r (prefix maximum of hi) and no row > r reaches a node <= r (suffix minimum of lo).  One block; thread t
+// owns the rows [t k, (t + 1) k), k = ceil(n / 1024): it scans them itself and the block scans the threads' totals,
+// so the number of barriers does not grow with n.  `lo` is overwritten by the suffix minima.
+__global__ void __launch_bounds__(kScanBlock) k_islands_build(const int32_t* __restrict__ rowptr, int n, int32_t* lo,
+                                                              const int32_t* __restrict__ hi,
+                                                              int32_t* __restrict__ island_ptr, int32_t* __restrict__ meta) {
+  __shared__ int sm[16];
+  __shared__ int max_nodes, max_edges;
   const int t = threadIdx.x;
-  const int chunks = (n + kScanBlock - 1) / kScanBlock;
+  const int k = (n + kScanBlock - 1) / kScanBlock;
+  const int r0 = t * k < n ? t * k : n, r1 = (t + 1) * k < n ? (t + 1) * k : n;
   auto imin = [](int a, int b) { return a < b ? a : b; };
   auto imax = [](int a, int b) { return a > b ? a : b; };
   auto iadd = [](int a, int b) { return a + b; };
-  if (t == 0) { carry = INT_MAX; count = 0; max_nodes = 0; max_edges = 0; island_ptr[0] = 0; }
+  if (t == 0) { max_nodes = 0; max_edges = 0; island_ptr[0] = 0; }
+  // suffix minimum of lo over the rows AFTER r: the thread's own rows from the back, then the later threads' totals
+  int mine = INT_MAX;
+  for (int r = r0; r < r1; ++r) mine = imin(mine, lo[r]);
+  // a scan over the threads in reverse order = a forward scan of the mirrored values
+  __shared__ int totals[kScanBlock];
+  totals[kScanBlock - 1 - t] = mine;
   __syncthreads();
-  for (int ch = chunks - 1; ch >= 0; --ch) {   // thread t takes the chunk's rows from the back: a prefix scan = suffix
-    const int r = ch * kScanBlock + (kScanBlock - 1 - t);
-    int lo = INT_MAX;
-    if (r < n) {
-      lo = r;
-      for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) lo = imin(lo, col[e]);
-    }
-    const int incl = block_scan_inclusive(lo, sm, imin);
-    const int c = carry;
-    sm[t] = incl;
-    __syncthreads();
-    const int excl = t > 0 ? imin(sm[t - 1], c) : c;   // rows after r
-    if (r < n) sufmin[r] = excl;
-    __syncthreads();
-    if (t == kScanBlock - 1) carry = imin(incl, c);
-    __syncthreads();
-  }
-  if (t == 0) carry = -1;
+  const int mirrored = block_scan_inclusive(totals[t], sm, imin);   // min over threads >= (1023 - t)
+  totals[t] = mirrored;
   __syncthreads();
-  for (int ch = 0; ch < chunks; ++ch) {
-    const int r = ch * kScanBlock + t;
-    int hi = -1;
-    if (r < n) {
-      hi = r;
-      for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) hi = imax(hi, col[e]);
-    }
-    const int pm = imax(block_scan_inclusive(hi, sm, imax), carry);
-    const int cut = r < n && pm <= r && sufmin[r] > r;
-    const int pos = block_scan_inclusive(cut, sm, iadd);
-    const int base = count;
-    if (cut) island_ptr[base + pos] = r + 1;
-    __syncthreads();
-    if (t == kScanBlock - 1) { carry = pm; count = base + pos; }
-    __syncthreads();
+  int after = t + 1 < kScanBlock ? totals[kScanBlock - 2 - t] : INT_MAX;   // min over threads > t
+  __syncthreads();
+  for (int r = r1 - 1; r >= r0; --r) {
+    const int v = lo[r];
+    lo[r] = after;
+    after = imin(after, v);
   }
-  const int islands = count;
+  // prefix maximum of hi up to and including r
+  int top = -1;
+  for (int r = r0; r < r1; ++r) top = imax(top, hi[r]);
+  const int incl = block_scan_inclusive(top, sm, imax);
+  totals[t] = incl;
+  __syncthreads();
+  int before = t > 0 ? totals[t - 1] : -1;   // max over threads < t
+  __syncthreads();
+  int cuts = 0;
+  for (int r = r0; r < r1; ++r) {
+    before = imax(before, hi[r]);
+    cuts += (before <= r && lo[r] > r) ? 1 : 0;
+  }
+  const int upto = block_scan_inclusive(cuts, sm, iadd);
+  int pos = upto - cuts;   // cuts of the threads before this one
+  before = t > 0 ? totals[t - 1] : -1;
+  for (int r = r0; r < r1; ++r) {
+    before = imax(before, hi[r]);
+    if (before <= r && lo[r] > r) island_ptr[++pos] = r + 1;
+  }
+  totals[t] = upto;
+  __syncthreads();
+  const int islands = totals[kScanBlock - 1];
   int mn = 0, me = 0;
   for (int i = t; i < islands; i += kScanBlock) {
     const int b = island_ptr[i], e = island_ptr[i + 1];
@@ -173,10 +190,22 @@ __device__ __forceinline__ void wave_sync() {   // LDS written by other lanes of
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ float wave_sum(float v) {   // the same bits in every lane
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-  return v;
+// Sum over the 64 lanes, the same bits in every lane: data-parallel-primitive adds inside each row of 16 lanes
+// (lane pairs, quads, mirrored halves, mirrored row), then the rows' sums passed on to the next row, and the total
+// read from the last lane.  Six vector adds instead of six round trips through the LDS crossbar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+  return v + __int_as_float(moved);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1, 0, 3, 2]
+  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2, 3, 0, 1]
+  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);   // row_mirror: every lane holds the sum of its row of 16
+  v = dpp_add<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3: rows 0+1, 2+3
+  v = dpp_add<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3: row 3 holds all four
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <typename T>
@@ -190,162 +219,212 @@ __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
                      __uint_as_float(t.y & 0xffff0000u));
 }
 
-// A wave runs alone on its SIMD (the tiles fill the LDS), so nothing hides the latency of a load but the wave's
-// own instruction stream: the dense loops below fetch the weights of a whole chunk of the contraction first (all
-// loads in flight together, addresses clamped instead of branches) and multiply afterwards.
+// The dense products run on the float32 matrix cores (v_mfma_f32_32x32x2f32): an island's tile is 32 rows tall,
+// which is the height of one MFMA tile, and a matrix-core operand is one value per lane - no operand has to be
+// broadcast to all lanes through the LDS, which is what bounds the same products written as per-lane fma chains.
+// Operand layout: A[m][k] sits in lane (m, k) = (lane % 32, lane / 32), B[k][n] in lane (n, k), and the
+// accumulator's register i of lane (n, h) is D[8 (i / 4) + 4 h + i % 4][n].  The two contraction indices of one
+// instruction may be any two, as long as A and B agree: lane half h takes the 4 consecutive indices 8 s + 4 h .. + 3
+// of step s (one 16-byte read) and feeds them to 4 instructions.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// acc[i][j] += sum_k in[i * ldin + col(k)] * W[(lane + 64 j) * ldw + k], k ascending: 8 rows of an LDS tile times the
-// transposed weight rows of the lane's output columns (the Linear layout, models/layers.py:84-87).  Tile column of
-// contraction index k: k below `split`, k + pad from there on (the tile holds [x | zero pad | aggr]).
-template <typename T, int CP, bool VEC>
-__device__ __forceinline__ void rows_times_wt(float (&acc)[8][CP], const float* in, int ldin, int K, int split, int pad,
-                                              const T* W, int64_t ldw, int lane) {
-  constexpr int Q = CP >= 4 ? 8 : 16;
-  const T* wrow[CP];
+__device__ __forceinline__ int acc_row(int i, int lh) { return 8 * (i >> 2) + 4 * lh + (i & 3); }
+
+__device__ __forceinline__ void mfma4(f32x16& c, const float4& a, const float4& b) {
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, c, 0, 0, 0);
+}
+
+// acc[t] += in[32 x K] * W[c0 + 32 t .. + 31][K]^T: the tile's rows times the transposed weight rows of 32 NT output
+// columns (the Linear layout, models/layers.py:84-87).  Contraction index k sits in tile column k below `split`
+// and k + pad from there on (the tile holds [x | zero pad | aggr]).  VEC: K, split and the row starts are multiples
+// of 4 and pad = 0.  The loads of a 64-wide chunk of the contraction are issued together, ahead of its MFMAs.
+// XG: the A operand comes straight from the global rows of x (`xrow` = this lane's row, `row_ok` = it exists)
+// instead of from the tile - for shapes whose tile would not leave room for four waves per block.
+template <typename T, int NT, bool VEC, bool XG = false>
+__device__ __forceinline__ void mm_wt(f32x16 (&acc)[NT], const float* in, int pitch, int K, int split, int pad, const T* W,
+                                      int64_t ldw, int c0, int li, int lh, const T* xrow = nullptr, bool row_ok = false) {
+  auto four = [&](auto get, int k) __attribute__((always_inline)) {   // get(k) for k .. k + 3, zero past K
+    float v[4];
 #pragma unroll
-  for (int j = 0; j < CP; ++j) wrow[j] = W + (int64_t)(lane + 64 * j) * ldw;
-  if constexpr (VEC) {   // K, split and the row starts are multiples of 4, pad = 0
-    for (int k0 = 0; k0 < K; k0 += 4 * Q) {
-      float4 w[CP][Q];
+    for (int q = 0; q < 4; ++q) {   // the load itself is unconditional (index clamped): no branch per element
+      const float t = get(k + q < K ? k + q : K - 1);
+      v[q] = k + q < K ? t : 0.f;
+    }
+    return make_float4(v[0], v[1], v[2], v[3]);
+  };
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    float4 af[8];
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int k = k0 + 4 * q < K ? k0 + 4 * q : K - 4;
-#pragma unroll
-        for (int j = 0; j < CP; ++j) w[j][q] = load4<T>(wrow[j] + k);
+    for (int s = 0; s < 8; ++s) {
+      if (k0 + 8 * s >= K) break;   // (uniform) steps past the end of the contraction: nothing to load or multiply
+      const int k = k0 + 8 * s + 4 * lh;
+      if constexpr (XG) {
+        af[s] = load4<T>(xrow + (k < K ? k : K - 4));
+        if (k >= K || !row_ok) af[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if constexpr (VEC) {
+        af[s] = *reinterpret_cast<const float4*>(in + li * pitch + (k < K ? k : K - 4));
+        if (k >= K) af[s] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+      else af[s] = four([&](int kk) __attribute__((always_inline)) { return in[li * pitch + (kk < split ? kk : kk + pad)]; }, k);
+    }
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        if (k0 + 4 * q < K) {
+    for (int t = 0; t < NT; ++t) {
+      const T* wr = W + (int64_t)(c0 + 32 * t + li) * ldw;
+      float4 bf[8];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(in + i * ldin + k0 + 4 * q);
-#pragma unroll
-            for (int j = 0; j < CP; ++j) {
-              acc[i][j] = fmaf(v.x, w[j][q].x, acc[i][j]);
-              acc[i][j] = fmaf(v.y, w[j][q].y, acc[i][j]);
-              acc[i][j] = fmaf(v.z, w[j][q].z, acc[i][j]);
-              acc[i][j] = fmaf(v.w, w[j][q].w, acc[i][j]);
-            }
-          }
+      for (int s = 0; s < 8; ++s) {
+        if (k0 + 8 * s >= K) break;
+        const int k = k0 + 8 * s + 4 * lh;
+        if constexpr (VEC) {
+          bf[s] = load4<T>(wr + (k < K ? k : K - 4));
+          if (k >= K) bf[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        else bf[s] = four([&](int kk) __attribute__((always_inline)) { return scalar_to_f32<T>(wr[kk]); }, k);
       }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        if (k0 + 8 * s >= K) break;
+        mfma4(acc[t], af[s], bf[s]);
+      }
+    }
+  }
+}
+
+// acc[t] += in[32 x C] * W[C][col0 + 32 t .. + 31]: the tile's rows times weight columns (C a multiple of 32); the
+// lanes of a half read consecutive columns of one weight row.  Columns from `ncols` on count as zero.
+template <typename T, int NT>
+__device__ __forceinline__ void mm_w(f32x16 (&acc)[NT], const float* in, int pitch, int C, const T* W, int64_t ldw,
+                                     int col0, int ncols, int li, int lh) {
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    float4 af[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) af[s] = *reinterpret_cast<const float4*>(in + li * pitch + c0 + 8 * s + 4 * lh);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = col0 + 32 * t + li;
+      const bool ok = col < ncols;
+      float4 bf[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const T* wp = W + (int64_t)(c0 + 8 * s + 4 * lh) * ldw + (ok ? col : 0);   // unconditional load, then select
+        const float4 v = make_float4(scalar_to_f32<T>(wp[0]), scalar_to_f32<T>(wp[ldw]), scalar_to_f32<T>(wp[2 * ldw]),
+                                     scalar_to_f32<T>(wp[3 * ldw]));
+        bf[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) mfma4(acc[t], af[s], bf[s]);
+    }
+  }
+}
+
+// One 32 x 32 tile of a block-wide weight-gradient product: out[c0 + m][col0 + n] = sum over the rows of every
+// wave's tile of left[row][c0 + m] * right[row][col0 + n] (right column j sits at tile column j below `split`, at
+// j + pad from there on; columns from K on are not written).  XG: right columns below `split` are columns of x,
+// read from global memory (island w2 starts at node n0s[w2]).  Waves in order, rows in ascending pairs; rows past
+// a tile's last node hold zeros.  All operand reads of one island go out together, ahead of its MFMAs.
+template <typename T, bool XG>
+__device__ __forceinline__ void block_outer(float* out, int K, int c0, int col0, const float* tiles, int wave_floats,
+                                            const int* nrows, const int* n0s, int wpb, int left, int ldl, int right,
+                                            int ldr, int split, int pad, const T* x, int64_t ldx, int li, int lh) {
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const int col = col0 + li;
+  const bool ok = col < K;
+  const bool from_x = XG && col0 < split;   // uniform: a 32-column tile lies on one side (split is a multiple of 32
+                                            // whenever XG is chosen) or is cut by `ok`
+  const int roff = right + (ok ? (col < split ? col : col + pad) : 0);
+  if (from_x) {
+    // global operand: the rows of all (at most 4) islands of the block requested before the first multiply
+    float bx[4][16];
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int nr = w2 < wpb ? nrows[w2] : 0;
+      const int64_t base = w2 < wpb ? n0s[w2] : 0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 2 * q + lh;
+        const bool live = ok && row < nr;
+        const float v = scalar_to_f32<T>(x[live ? (base + row) * ldx + col : 0]);
+        bx[w2][q] = live ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      if (w2 >= wpb) break;
+      const float* tb = tiles + w2 * wave_floats;
+      const int nr = nrows[w2];
+      float av[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) av[q] = tb[left + (2 * q + lh) * ldl + c0 + li];
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (2 * q < nr) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bx[w2][q], acc, 0, 0, 0);
     }
   } else {
-    for (int k0 = 0; k0 < K; k0 += Q) {
-      float w[CP][Q];
+    for (int w2 = 0; w2 < wpb; ++w2) {
+      const float* tb = tiles + w2 * wave_floats;
+      const int nr = nrows[w2];
+      if (nr == 0) continue;
+      float av[16], bv[16];
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int k = k0 + q < K ? k0 + q : K - 1;
-#pragma unroll
-        for (int j = 0; j < CP; ++j) w[j][q] = scalar_to_f32<T>(wrow[j][k]);
+      for (int q = 0; q < 16; ++q) {
+        const int row = 2 * q + lh;   // < 32: the tile is 32 rows tall
+        av[q] = tb[left + row * ldl + c0 + li];
+        bv[q] = ok ? tb[roff + row * ldr] : 0.f;
       }
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int k = k0 + q;
-        if (k < K) {
-          const int xc = k < split ? k : k + pad;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const float v = in[i * ldin + xc];
-#pragma unroll
-            for (int j = 0; j < CP; ++j) acc[i][j] = fmaf(v, w[j][q], acc[i][j]);
-          }
-        }
-      }
+      for (int q = 0; q < 16; ++q)
+        if (2 * q < nr) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
     }
   }
+  if (ok) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out[(int64_t)(c0 + acc_row(i, lh)) * K + col] = acc[i];
+  }
 }
 
-// acc[i][j] += sum_c in[i * ldin + c] * W[c * ldw + col[j]], c ascending (C a multiple of 32): 8 rows of an LDS tile
-// times weight columns, the lanes reading consecutive columns of one weight row.
-template <typename T>
-__device__ __forceinline__ void rows_times_w(float (&acc)[8][2], const float* in, int ldin, int C, const T* W,
-                                             int64_t ldw, const int (&col)[2], const bool (&ok)[2]) {
-  for (int c0 = 0; c0 < C; c0 += 32) {
-    float w[32][2];
-#pragma unroll
-    for (int q = 0; q < 32; ++q)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) w[q][j] = ok[j] ? scalar_to_f32<T>(W[(int64_t)(c0 + q) * ldw + col[j]]) : 0.f;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float4 v = *reinterpret_cast<const float4*>(in + i * ldin + c0 + 4 * q);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = fmaf(v.x, w[4 * q][j], acc[i][j]);
-          acc[i][j] = fmaf(v.y, w[4 * q + 1][j], acc[i][j]);
-          acc[i][j] = fmaf(v.z, w[4 * q + 2][j], acc[i][j]);
-          acc[i][j] = fmaf(v.w, w[4 * q + 3][j], acc[i][j]);
-        }
-      }
+// Per-wave LDS, in floats; every tile is kTileRows tall.  xa [32][px]: the rows of x, zero columns up to a
+// multiple of 4, then the sums over edges; ab [32][pab]: the projection [A | B]; (backward) gz [32][pz]; the
+// staging area of the edge loops; (EGNN) pos, and in the backward the gradients arriving at pos' and collected for
+// pos, 4 floats per node.  Row pitches are odd multiples of 4 floats, so that the 16-byte operand reads of 8
+// consecutive rows fall into different banks.
+constexpr int kTileRows = 32;
+constexpr int kStageEdges = 32;
+__host__ __device__ inline int island_pitch(int width) { return width % 8 == 4 ? width : width + 4; }   // width % 4 == 0
+__host__ __device__ inline int island_stage_floats(int Fe) { return kTileRows + 8 + kStageEdges + kStageEdges * kIslandFeMax; }
+__host__ __device__ inline int island_wave_floats(int F, int H, int Fe, bool egnn, bool backward, bool xg = false) {
+  const int Fp = xg ? 0 : (F + 3) & ~3;   // xg: the rows of x stay in global memory
+  return kTileRows * (island_pitch(Fp + H) + island_pitch(2 * H) + (backward ? island_pitch(H) : 0)) +
+         (island_stage_floats(Fe) + 3) / 4 * 4 + (egnn ? kTileRows * 4 * (backward ? 3 : 1) : 0);
+}
+
+// Rows [n0, n0 + n) of x into the tile's first F columns (zero rows below, zero pad columns).  The iterations are
+// independent: unrolled, their loads are in flight together.
+template <typename T, bool VEC>
+__device__ __forceinline__ void load_rows(float* xa, int px, const T* x, int64_t ldx, int n0, int n, int F, int Fp, int lane) {
+  if constexpr (VEC) {   // F % 4 == 0 (Fp = F): 4 columns per lane and step
+    const int per_row = F >> 2;
+#pragma unroll 8
+    for (int i = lane; i < kTileRows * per_row; i += 64) {
+      const int r = i / per_row, k = 4 * (i - r * per_row);
+      const int rc = r < n ? r : n - 1;
+      const T* p = x + (int64_t)(n0 + rc) * ldx + k;
+      float4 v = make_float4(scalar_to_f32<T>(p[0]), scalar_to_f32<T>(p[1]), scalar_to_f32<T>(p[2]), scalar_to_f32<T>(p[3]));
+      if (r >= n) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(xa + r * px + k) = v;
     }
-  }
-}
-
-// One task of a block-wide weight-gradient product: out[(c0 + i) * K + col] = sum over the rows of every wave's tile
-// of left[row][c0 + i] * right[row][col], i < 16, col = kbase + lane + 64 j.  Right column `col` sits at tile column
-// col below `split` and at col + pad from there on.  Waves in order, rows in order.
-__device__ __forceinline__ void block_outer(float* out, int K, int c0, int kbase, const float* tiles, int wave_floats,
-                                            const int* nrows, int wpb, int left, int ldl, int right, int ldr, int split,
-                                            int pad, int lane) {
-  float acc[16][2];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i][0] = acc[i][1] = 0.f;
-  int off[2], col[2];
-  bool ok[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    col[j] = kbase + lane + 64 * j;
-    ok[j] = col[j] < K;
-    off[j] = ok[j] ? right + (col[j] < split ? col[j] : col[j] + pad) : right;
-  }
-  for (int w2 = 0; w2 < wpb; ++w2) {
-    const float* tb = tiles + w2 * wave_floats;
-    const int nr = nrows[w2];
-    for (int r = 0; r < nr; ++r) {
-      float lv[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(tb + left + r * ldl + c0 + 4 * q);
-        lv[4 * q] = v.x; lv[4 * q + 1] = v.y; lv[4 * q + 2] = v.z; lv[4 * q + 3] = v.w;
-      }
-      float rv[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) rv[j] = ok[j] ? tb[off[j] + r * ldr] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        acc[i][0] = fmaf(lv[i], rv[0], acc[i][0]);
-        acc[i][1] = fmaf(lv[i], rv[1], acc[i][1]);
-      }
+  } else {
+#pragma unroll 4
+    for (int i = lane; i < kTileRows * Fp; i += 64) {
+      const int r = i / Fp, k = i - r * Fp;
+      const int rc = r < n ? r : n - 1, kc = k < F ? k : F - 1;
+      const float v = scalar_to_f32<T>(x[(int64_t)(n0 + rc) * ldx + kc]);
+      xa[r * px + k] = (r < n && k < F) ? v : 0.f;
     }
-  }
-#pragma unroll
-  for (int i = 0; i < 16; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      if (ok[j]) out[(int64_t)(c0 + i) * K + col[j]] = acc[i][j];
-}
-
-// Per-wave LDS, in floats.  xa [R][P]: the rows of x, zero columns up to a multiple of 4, then the sums over edges
-// (P = Fp + H); ab [R][2H]; (backward) gz [R][H]; the staging area of the edge loops; (EGNN) pos, and in the
-// backward the gradients arriving at pos' and collected for pos, 4 floats per node.
-constexpr int kStageEdges = 64;
-__host__ __device__ inline int island_stage_floats(int rows) { return rows + 8 + kStageEdges + kStageEdges * kIslandFeMax; }
-__host__ __device__ inline int island_wave_floats(int rows, int F, int H, bool egnn, bool backward) {
-  const int Fp = (F + 3) & ~3;
-  return rows * (Fp + H) + rows * 2 * H + (backward ? rows * H : 0) + island_stage_floats(rows) +
-         (egnn ? rows * 4 * (backward ? 3 : 1) : 0);
-}
-
-// Rows [n0, n0 + n) of x into the tile's first F columns (zero rows up to rn, zero pad columns).
-template <typename T>
-__device__ __forceinline__ void load_rows(float* xa, int P, const T* x, int64_t ldx, int n0, int n, int rn, int F, int Fp,
-                                          int lane) {
-  for (int i = lane; i < rn * Fp; i += 64) {
-    const int r = i / Fp, k = i - r * Fp;
-    xa[r * P + k] = (r < n && k < F) ? scalar_to_f32<T>(x[(int64_t)(n0 + r) * ldx + k]) : 0.f;
   }
 }
 
@@ -364,25 +443,26 @@ struct EdgeWeights {
     }
   }
   // We[c, :] . e as an fma chain in feature order (the order of the general edge kernels)
-  __device__ __forceinline__ float term(int j, const float (&ev)[kIslandFeMax], int Fe) const {
+  // (all 8 terms: weights and attributes past the real width are zeros, and adding an exact zero changes nothing)
+  __device__ __forceinline__ float term(int j, const float (&ev)[kIslandFeMax]) const {
     float s = we[j][0] * ev[0];
 #pragma unroll
-    for (int d = 1; d < kIslandFeMax; ++d)
-      if (d < Fe) s = fmaf(we[j][d], ev[d], s);
+    for (int d = 1; d < kIslandFeMax; ++d) s = fmaf(we[j][d], ev[d], s);
     return s;
   }
 };
 
-// Walks the island's edges in CSR order: begin(r) when row r starts, edge(r, s, ev) for every edge into r from local
-// node s with attributes ev, end(r) when the row is complete; rows without edges get begin and end too.  The row
-// pointers, source ids and attributes pass through LDS in coalesced pieces of 64 edges, so that the walk itself
-// waits for no global load.
-template <typename T, typename Begin, typename Edge, typename End>
+// Walks the island's edges in CSR order: begin(r) when row r starts, edge(r, s, ev, f) for every edge into r from
+// local node s with attributes ev, end(r) when the row is complete; rows without edges get begin and end too.
+// f = fetch(s) is what the edge needs of its source's rows (read ahead of use, four edges at a time, since a wave
+// that runs alone on its SIMD has nothing else to cover an LDS round trip per edge).  The row pointers, source ids
+// and attributes pass through LDS in coalesced pieces of 32 edges, so that the walk waits for no global load.
+template <typename T, typename Fetched, typename Begin, typename Fetch, typename Edge, typename End>
 __device__ __forceinline__ void walk_edges(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                           const T* __restrict__ ea, int Fe, int rows, float* stage, int n0, int n, int lane,
-                                           Begin begin, Edge edge, End end) {
+                                           const T* __restrict__ ea, int Fe, float* stage, int n0, int n, int lane,
+                                           Begin begin, Fetch fetch, Edge edge, End end) {
   int* rp = reinterpret_cast<int*>(stage);
-  int* ecol = rp + rows + 8;
+  int* ecol = rp + kTileRows + 8;
   float* eat = reinterpret_cast<float*>(ecol + kStageEdges);
   for (int i = lane; i <= n; i += 64) rp[i] = rowptr[n0 + i];
   wave_sync();
@@ -393,24 +473,41 @@ __device__ __forceinline__ void walk_edges(const int32_t* __restrict__ rowptr, c
   for (int eb = e_first; eb < e_last; eb += kStageEdges) {
     const int cnt = e_last - eb < kStageEdges ? e_last - eb : kStageEdges;
     if (lane < cnt) ecol[lane] = col[eb + lane] - n0;
-    for (int i = lane; i < cnt * Fe; i += 64) {
-      const int q = i / Fe;
-      eat[q * kIslandFeMax + (i - q * Fe)] = scalar_to_f32<T>(ea[(int64_t)eb * Fe + i]);
+    for (int i = lane; i < cnt * kIslandFeMax; i += 64) {   // rows of 8 floats, zeros past the real width
+      const int q = i >> 3, d = i & 7;
+      eat[i] = d < Fe ? scalar_to_f32<T>(ea[(int64_t)(eb + q) * Fe + d]) : 0.f;
     }
     wave_sync();
-    for (int i = 0; i < cnt; ++i) {
-      while (eb + i >= row_end) {
-        end(r);
-        ++r;
-        row_end = __builtin_amdgcn_readfirstlane(rp[r + 1]);
-        begin(r);
+    for (int i0 = 0; i0 < cnt; i0 += 4) {   // the LDS reads of 4 edges go out together; the edges are used in order
+      int sv[4];
+      float evv[4][kIslandFeMax];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = i0 + q < cnt ? i0 + q : cnt - 1;
+        sv[q] = ecol[i];
+        const float4 lo = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax);
+        const float4 hi = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax + 4);
+        evv[q][0] = lo.x; evv[q][1] = lo.y; evv[q][2] = lo.z; evv[q][3] = lo.w;
+        evv[q][4] = hi.x; evv[q][5] = hi.y; evv[q][6] = hi.z; evv[q][7] = hi.w;
       }
-      const int s = __builtin_amdgcn_readfirstlane(ecol[i]);
-      float ev[kIslandFeMax];
-      const float4 lo = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax);
-      const float4 hi = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax + 4);
-      ev[0] = lo.x; ev[1] = lo.y; ev[2] = lo.z; ev[3] = lo.w; ev[4] = hi.x; ev[5] = hi.y; ev[6] = hi.z; ev[7] = hi.w;
-      edge(r, s, ev);
+      Fetched f[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        sv[q] = __builtin_amdgcn_readfirstlane(sv[q]);
+        f[q] = fetch(sv[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (i0 + q < cnt) {
+          while (eb + i0 + q >= row_end) {
+            end(r);
+            ++r;
+            row_end = __builtin_amdgcn_readfirstlane(rp[r + 1]);
+            begin(r);
+          }
+          edge(r, sv[q], evv[q], f[q]);
+        }
+      }
     }
     wave_sync();
   }
@@ -421,63 +518,94 @@ __device__ __forceinline__ void walk_edges(const int32_t* __restrict__ rowptr, c
   }
 }
 
-// [A | B] = x Wn^T for the tile's rows (models/layers.py:104-105).
-template <typename T, int CPL, bool VEC>
-__device__ __forceinline__ void project(const IslandLayer& a, const float* xa, int P, float* ab, int rn, int lane) {
-  constexpr int H = 64 * CPL;
-  for (int r0 = 0; r0 < rn; r0 += 8) {
-    float acc[8][2 * CPL];
+// Stores a wave's accumulator tile: put(row, value) for the lane's 16 rows of its column.
+template <typename Put>
+__device__ __forceinline__ void for_acc(const f32x16& acc, int lh, Put put) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 2 * CPL; ++j) acc[i][j] = 0.f;
-    rows_times_wt<T, 2 * CPL, VEC>(acc, xa + r0 * P, P, a.F, a.F, 0, static_cast<const T*>(a.w_nodes), a.F, lane);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 2 * CPL; ++j) ab[(r0 + i) * 2 * H + lane + 64 * j] = acc[i][j];
-  }
+  for (int i = 0; i < 16; ++i) put(acc_row(i, lh), acc[i]);
 }
+
+// [A | B] = x Wn^T for the tile's rows (models/layers.py:104-105).
+template <typename T, int CPL, bool VEC, bool XG = false>
+__device__ __forceinline__ void project(const IslandLayer& a, const float* xa, int px, float* ab, int pab, int li, int lh,
+                                        int n0 = 0, int n = 0) {
+  constexpr int NT = 4 * CPL;   // 2 H / 32 column tiles
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const T* xrow = XG ? static_cast<const T*>(a.x) + (int64_t)(n0 + (li < n ? li : n - 1)) * a.ldx : nullptr;
+  mm_wt<T, NT, VEC, XG>(acc, xa, px, a.F, a.F, 0, static_cast<const T*>(a.w_nodes), a.F, 0, li, lh, xrow, li < n);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    for_acc(acc[t], lh, [&](int row, float v) __attribute__((always_inline)) { ab[row * pab + 32 * t + li] = v; });
+}
+
+template <int CPL>
+struct SourceRow { float b[CPL]; float px, py, pz; };   // the lane's columns of B[s]; the coordinates of s (EGNN)
+template <int CPL>
+using SourceRowBwd = SourceRow<CPL>;
 
 // Messages of the island's edges summed per destination (models/layers.py:128 and the add-aggregation) into the
 // tile's aggr columns, plus the coordinate update of the EGNN form: pos'[n] = pos[n] + sum (pos[n] - pos[src]) *
 // (w_pos . m).
 template <typename T, int CPL, bool EGNN>
 __device__ __forceinline__ void edges_forward(const IslandLayer& a, const EdgeWeights<T, CPL, EGNN>& ew, const float* ab,
-                                              float* ag, int P, const float* ps, float* stage, int n0, int n, int lane,
-                                              bool write_pos) {
+                                              int pab, float* ag, int pag, const float* ps, float* stage, int n0, int n,
+                                              int lane, bool write_pos) {
   constexpr int H = 64 * CPL;
   float av[CPL], sum[CPL];
-  float pacc = 0.f;                      // lane c < 3: component c of the row's coordinate update
-  const int pc = lane < 3 ? lane : 3;    // (the fourth float of a node's coordinates is a zero pad)
+  // coordinate update of a row: sum_e rel_e (w_pos . m_e) = sum_c w_pos[c] (sum_e rel_e m_e[c]) - the lane keeps the
+  // inner sums of its columns, and the sum over the columns is taken once per row instead of once per edge
+  float vx = 0.f, vy = 0.f, vz = 0.f;
   const int Fe = a.Fe;
   float* const pos_out = a.pos_out;
-  walk_edges<T>(
-      a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, a.rows, stage, n0, n, lane,
+  float prx = 0.f, pry = 0.f, prz = 0.f;
+  walk_edges<T, SourceRow<CPL>>(
+      a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, stage, n0, n, lane,
       [&](int r) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) { av[j] = ab[r * 2 * H + lane + 64 * j]; sum[j] = 0.f; }
-        pacc = 0.f;
+        for (int j = 0; j < CPL; ++j) { av[j] = ab[r * pab + lane + 64 * j]; sum[j] = 0.f; }
+        vx = vy = vz = 0.f;
+        if constexpr (EGNN) { prx = ps[4 * r]; pry = ps[4 * r + 1]; prz = ps[4 * r + 2]; }
       },
-      [&](int r, int s, const float (&ev)[kIslandFeMax]) __attribute__((always_inline)) {
-        float dot = 0.f;
+      [&](int s) __attribute__((always_inline)) {
+        SourceRow<CPL> f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) f.b[j] = ab[s * pab + H + lane + 64 * j];
+        f.px = EGNN ? ps[4 * s] : 0.f;
+        f.py = EGNN ? ps[4 * s + 1] : 0.f;
+        f.pz = EGNN ? ps[4 * s + 2] : 0.f;
+        return f;
+      },
+      [&](int r, int s, const float (&ev)[kIslandFeMax], const SourceRow<CPL>& f) __attribute__((always_inline)) {
+        float wm = 0.f;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-          const float pre = (av[j] + ab[s * 2 * H + H + lane + 64 * j]) + ew.term(j, ev, Fe);
+          const float pre = (av[j] + f.b[j]) + ew.term(j, ev);
           const float m = fmaxf(pre, 0.f);
           sum[j] += m;
-          if constexpr (EGNN) dot = fmaf(ew.wp[j], m, dot);
+          if constexpr (EGNN) wm = fmaf(ew.wp[j], m, wm);
         }
         if constexpr (EGNN) {
-          const float sc = wave_sum(dot);
-          pacc = fmaf(ps[4 * r + pc] - ps[4 * s + pc], sc, pacc);
+          vx = fmaf(prx - f.px, wm, vx);
+          vy = fmaf(pry - f.py, wm, vy);
+          vz = fmaf(prz - f.pz, wm, vz);
         }
       },
       [&](int r) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) ag[r * P + lane + 64 * j] = sum[j];
+        for (int j = 0; j < CPL; ++j) ag[r * pag + lane + 64 * j] = sum[j];
         if constexpr (EGNN) {
-          if (write_pos && lane < 3) pos_out[(int64_t)(n0 + r) * 3 + lane] = ps[4 * r + lane] + pacc;
+          if (write_pos) {
+            const float dx = wave_sum(vx), dy = wave_sum(vy), dz = wave_sum(vz);
+            if (lane == 0) {
+              pos_out[(int64_t)(n0 + r) * 3] = prx + dx;
+              pos_out[(int64_t)(n0 + r) * 3 + 1] = pry + dy;
+              pos_out[(int64_t)(n0 + r) * 3 + 2] = prz + dz;
+            }
+          }
         }
       });
 }
@@ -486,48 +614,63 @@ template <typename T, int CPL, bool EGNN, bool VEC>
 __global__ void __launch_bounds__(256) k_island_fwd(IslandLayer a) {
   extern __shared__ __align__(16) float lds[];
   constexpr int H = 64 * CPL;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
-  const int F = a.F, Fp = (F + 3) & ~3, P = Fp + H, R = a.rows;
-  float* xa = lds + kIslandHeader + w * island_wave_floats(R, F, H, EGNN, false);
-  float* ab = xa + R * P;
-  float* stage = ab + R * 2 * H;
-  float* ps = stage + island_stage_floats(R);
+  const int F = a.F, Fp = (F + 3) & ~3;
+  const int px = island_pitch(Fp + H), pab = island_pitch(2 * H);
+  float* xa = lds + kIslandHeader + w * island_wave_floats(F, H, a.Fe, EGNN, false);
+  float* ab = xa + kTileRows * px;
+  float* stage = ab + kTileRows * pab;
+  float* ps = stage + (island_stage_floats(a.Fe) + 3) / 4 * 4;
   const Unit un = island_unit(a, blockIdx.x * wpb + w);
   if (un.n == 0) return;
-  const int n = un.n, n0 = un.n0, rn = (n + 7) & ~7;
+  const int n = un.n, n0 = un.n0;
   ISLAND_PROF(0);
-  load_rows<T>(xa, P, static_cast<const T*>(a.x), a.ldx, n0, n, rn, F, Fp, lane);
+  load_rows<T, VEC>(xa, px, static_cast<const T*>(a.x), a.ldx, n0, n, F, Fp, lane);
+  if ((int)blockIdx.x * wpb + w >= a.n_islands) {
+    // A tile of the edgeless tail: when its rows of x are zeros (the padding of a fixed-capacity batch) the layer's
+    // output is relu(0) = 0 exactly and the coordinates pass through - nothing to multiply.
+    wave_sync();
+    bool nz = false;
+    for (int i = lane; i < n * Fp; i += 64) nz |= xa[(i / Fp) * px + i % Fp] != 0.f;
+    if (!__any(nz)) {
+      T* y = static_cast<T*>(a.y);
+      for (int i = lane; i < n * H; i += 64) y[(int64_t)(n0 + i / H) * a.ldy + (i & (H - 1))] = f32_to_scalar<T>(0.f);
+      if constexpr (EGNN)
+        for (int i = lane; i < n * 3; i += 64) a.pos_out[(int64_t)n0 * 3 + i] = a.pos[(int64_t)n0 * 3 + i];
+      return;
+    }
+  }
   if constexpr (EGNN)
     for (int i = lane; i < n * 4; i += 64) ps[i] = (i & 3) < 3 ? a.pos[(int64_t)(n0 + (i >> 2)) * 3 + (i & 3)] : 0.f;
   EdgeWeights<T, CPL, EGNN> ew;
   ew.load(a, lane);
   wave_sync();
   ISLAND_PROF(1);
-  project<T, CPL, VEC>(a, xa, P, ab, rn, lane);
+  project<T, CPL, VEC>(a, xa, px, ab, pab, li, lh);
   wave_sync();
   ISLAND_PROF(2);
-  edges_forward<T, CPL, EGNN>(a, ew, ab, xa + Fp, P, ps, stage, n0, n, lane, true);
-  for (int i = lane; i < (rn - n) * H; i += 64) xa[(n + i / H) * P + Fp + (i & (H - 1))] = 0.f;
+  edges_forward<T, CPL, EGNN>(a, ew, ab, pab, xa + Fp, px, ps, stage, n0, n, lane, true);
+  for (int i = lane; i < (kTileRows - n) * H; i += 64) xa[(n + i / H) * px + Fp + (i & (H - 1))] = 0.f;
   wave_sync();
   ISLAND_PROF(3);
   // y = relu([x | aggr] W_out^T) (models/layers.py:140)
-  T* y = static_cast<T*>(a.y);
-  for (int r0 = 0; r0 < rn; r0 += 8) {
-    float acc[8][CPL];
+  {
+    constexpr int NT = 2 * CPL;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) acc[i][j] = 0.f;
-    rows_times_wt<T, CPL, VEC>(acc, xa + r0 * P, P, F + H, F, Fp - F, static_cast<const T*>(a.w_out), F + H, lane);
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    mm_wt<T, NT, VEC>(acc, xa, px, F + H, F, Fp - F, static_cast<const T*>(a.w_out), F + H, 0, li, lh);
+    T* y = static_cast<T*>(a.y);
+    const int64_t ldy = a.ldy;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (r0 + i < n) {
-#pragma unroll
-        for (int j = 0; j < CPL; ++j)
-          y[(int64_t)(n0 + r0 + i) * a.ldy + lane + 64 * j] = f32_to_scalar<T>(fmaxf(acc[i][j], 0.f));
-      }
+    for (int t = 0; t < NT; ++t)
+      for_acc(acc[t], lh, [&](int row, float v) __attribute__((always_inline)) {
+        if (row < n) y[(int64_t)(n0 + row) * ldy + 32 * t + li] = f32_to_scalar<T>(fmaxf(v, 0.f));
+      });
   }
   ISLAND_PROF(4);
 }
@@ -538,38 +681,41 @@ __host__ __device__ inline int64_t island_partial_floats(int F, int H, int Fe, i
   return (v + 63) / 64 * 64;
 }
 
-template <typename T, int CPL, bool EGNN, bool VEC>
+template <typename T, int CPL, bool EGNN, bool VEC, bool XG>
 __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
   extern __shared__ __align__(16) float lds[];
   constexpr int H = 64 * CPL;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
-  const int F = a.F, Fp = (F + 3) & ~3, P = Fp + H, R = a.rows;
-  const int wave_floats = island_wave_floats(R, F, H, EGNN, true);
+  const int F = a.F, Fp = XG ? 0 : (F + 3) & ~3;   // XG: no columns of x in the tile
+  const int px = island_pitch(Fp + H), pab = island_pitch(2 * H), pz = island_pitch(H);
+  const int wave_floats = island_wave_floats(F, H, a.Fe, EGNN, true, XG);
   int* nrows = reinterpret_cast<int*>(lds);
+  int* n0s = nrows + 4;
   float* tiles = lds + kIslandHeader;
-  const int o_ab = R * P, o_gz = o_ab + R * 2 * H, o_stage = o_gz + R * H, o_ps = o_stage + island_stage_floats(R);
+  const int o_ab = kTileRows * px, o_gz = o_ab + kTileRows * pab, o_stage = o_gz + kTileRows * pz;
+  const int o_ps = o_stage + (island_stage_floats(a.Fe) + 3) / 4 * 4;
   float* xa = tiles + w * wave_floats;
   float* ab = xa + o_ab;
-  float* ag = xa + Fp;     // pitch P: sums over edges, later the gradient that reaches them
+  float* ag = xa + Fp;     // pitch px: sums over edges, later the gradient that reaches them
   float* gz = xa + o_gz;   // gy * [y > 0], later the gradient of B
   float* stage = xa + o_stage;
   float* ps = xa + o_ps;   // pos | gradient of pos' | gradient of pos (EGNN)
-  float* gp = ps + 4 * R;
-  float* gq = gp + 4 * R;
+  float* gp = ps + 4 * kTileRows;
+  float* gq = gp + 4 * kTileRows;
   float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
   const int64_t o_wn = (int64_t)H * (F + H), o_we = o_wn + (int64_t)2 * H * F, o_wp = o_we + (int64_t)wpb * H * a.Fe;
 
-  if ((int)blockIdx.x * wpb >= island_active_units(a.island_ptr, a.n_islands, a.tail_units, R, a.N)) return;   // whole block
+  if ((int)blockIdx.x * wpb >= island_active_units(a.island_ptr, a.n_islands, a.tail_units, kTileRows, a.N)) return;   // whole block
   const Unit un = island_unit(a, blockIdx.x * wpb + w);
-  const int n = un.n, n0 = un.n0, rn = (n + 7) & ~7;
-  if (lane == 0) nrows[w] = n;
+  const int n0 = un.n0;
+  int n = un.n;
   ISLAND_PROF(0);
   EdgeWeights<T, CPL, EGNN> ew;
   ew.load(a, lane);
   if (n > 0) {
-    load_rows<T>(xa, P, static_cast<const T*>(a.x), a.ldx, n0, n, rn, F, Fp, lane);
+    if constexpr (!XG) load_rows<T, VEC>(xa, px, static_cast<const T*>(a.x), a.ldx, n0, n, F, Fp, lane);
     if constexpr (EGNN) {
       for (int i = lane; i < n * 4; i += 64) {
         const bool c = (i & 3) < 3;
@@ -582,31 +728,52 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
     // gz = gy * [y > 0] (models/layers.py:140 backwards)
     const T* gy = static_cast<const T*>(a.gy);
     const T* y = static_cast<const T*>(a.y);
-    for (int i = lane; i < rn * H; i += 64) {
+    const int64_t ldy = a.ldy, ldgy = a.ldgy;
+#pragma unroll 8
+    for (int i = lane; i < kTileRows * H; i += 64) {   // both loads unconditional (row clamped): all in flight together
       const int r = i / H, c = i & (H - 1);
-      float g = 0.f;
-      if (r < n && scalar_to_f32<T>(y[(int64_t)(n0 + r) * a.ldy + c]) > 0.f)
-        g = scalar_to_f32<T>(gy[(int64_t)(n0 + r) * a.ldgy + c]);
-      gz[i] = g;
+      const int rc = r < n ? r : n - 1;
+      const float yv = scalar_to_f32<T>(y[(int64_t)(n0 + rc) * ldy + c]);
+      const float gv = scalar_to_f32<T>(gy[(int64_t)(n0 + rc) * ldgy + c]);
+      gz[r * pz + c] = (r < n && yv > 0.f) ? gv : 0.f;
     }
     wave_sync();
+    if ((int)blockIdx.x * wpb + w >= a.n_islands) {
+      // A tile of the edgeless tail that no gradient reaches through the relu (the padding rows of a
+      // fixed-capacity batch: their y is 0): every product below would be a product with zeros.  gx = 0, the
+      // coordinates' gradient passes through, and the tile takes no part in the weight gradients.
+      bool nz = false;
+      for (int i = lane; i < n * H; i += 64) nz |= gz[(i / H) * pz + (i & (H - 1))] != 0.f;
+      if (!__any(nz)) {
+        if (a.gx) {
+          T* gx = static_cast<T*>(a.gx);
+          for (int i = lane; i < n * F; i += 64) gx[(int64_t)(n0 + i / F) * a.ldgx + i % F] = f32_to_scalar<T>(0.f);
+        }
+        if constexpr (EGNN)
+          for (int i = lane; i < n * 3; i += 64) a.gpos[(int64_t)n0 * 3 + i] = a.gpos_out[(int64_t)n0 * 3 + i];
+        n = 0;
+      }
+    }
+  }
+  if (lane == 0) { nrows[w] = n; n0s[w] = n0; }
+  if (n > 0) {
     ISLAND_PROF(1);
-    project<T, CPL, VEC>(a, xa, P, ab, rn, lane);
+    project<T, CPL, VEC, XG>(a, xa, px, ab, pab, li, lh, n0, n);
     wave_sync();
     ISLAND_PROF(2);
-    edges_forward<T, CPL, EGNN>(a, ew, ab, ag, P, ps, stage, n0, n, lane, false);
-    for (int i = lane; i < (rn - n) * H; i += 64) ag[(n + i / H) * P + (i & (H - 1))] = 0.f;
+    edges_forward<T, CPL, EGNN>(a, ew, ab, pab, ag, px, ps, stage, n0, n, lane, false);
+    for (int i = lane; i < (kTileRows - n) * H; i += 64) ag[(n + i / H) * px + (i & (H - 1))] = 0.f;
     ISLAND_PROF(3);
   }
   __syncthreads();
   ISLAND_PROF(4);
   // gW_out = gz^T [x | aggr] over the rows of the whole block
   {
-    const int kgroups = (F + H + 127) / 128;
-    const int tasks = (H / 16) * kgroups;
+    const int ktiles = (F + H + 31) / 32;
+    const int tasks = (H / 32) * ktiles;
     for (int t = w; t < tasks; t += wpb)
-      block_outer(part, F + H, 16 * (t / kgroups), 128 * (t % kgroups), tiles, wave_floats, nrows, wpb, o_gz, H, 0, P, F,
-                  Fp - F, lane);
+      block_outer<T, XG>(part, F + H, 32 * (t / ktiles), 32 * (t % ktiles), tiles, wave_floats, nrows, n0s, wpb, o_gz, pz,
+                         0, px, F, Fp - F, static_cast<const T*>(a.x), a.ldx, li, lh);
   }
   ISLAND_PROF(5);
   __syncthreads();
@@ -620,53 +787,70 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
   }
   if (n > 0) {
     // [gx (first part) | ga] = gz W_out: the aggr columns always, the x columns when gx is wanted
-    const T* wo = static_cast<const T*>(a.w_out);
-    const int kfirst = a.gx ? 0 : F;
-    for (int kb = kfirst; kb < F + H; kb += 128) {
-      int col[2];
-      bool ok[2];
+    {
+      const T* wo = static_cast<const T*>(a.w_out);
+      float* const gx_part = a.gx_part;
+      const int first = a.gx ? 0 : (F / 32) * 32;    // the 32-column tile that holds column F
+      for (int col0 = first; col0 < F + H; col0 += 64) {
+        f32x16 acc[2];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) { col[j] = kb + lane + 64 * j; ok[j] = col[j] < F + H; }
-      for (int r0 = 0; r0 < rn; r0 += 8) {
-        float acc[8][2];
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i][0] = acc[i][1] = 0.f;
-        rows_times_w<T>(acc, gz + r0 * H, H, H, wo, F + H, col, ok);
+          for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+        mm_w<T, 2>(acc, gz, pz, H, wo, F + H, col0, F + H, li, lh);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            if (!ok[j]) continue;
-            if (col[j] >= F) ag[(r0 + i) * P + col[j] - F] = acc[i][j];
-            else if (r0 + i < n) a.gx_part[(int64_t)(n0 + r0 + i) * F + col[j]] = acc[i][j];
+        for (int t = 0; t < 2; ++t) {
+          const int col = col0 + 32 * t + li;
+          if (col >= F + H) continue;
+          if (col >= F) {
+            for_acc(acc[t], lh, [&](int row, float v) __attribute__((always_inline)) { ag[row * px + col - F] = v; });
+          } else if (gx_part) {
+            for_acc(acc[t], lh, [&](int row, float v) __attribute__((always_inline)) {
+              if (row < n) gx_part[(int64_t)(n0 + row) * F + col] = v;
+            });
           }
+        }
       }
     }
     wave_sync();
     ISLAND_PROF(7);
     // gz is dead: its slab collects the gradient of B
-    for (int i = lane; i < rn * H; i += 64) gz[i] = 0.f;
+    for (int i = lane; i < kTileRows * pz; i += 64) gz[i] = 0.f;
     wave_sync();
     float av[CPL], gar[CPL], ga_sum[CPL];
     float gpx = 0.f, gpy = 0.f, gpz = 0.f, sc_sum = 0.f;
     const int Fe = a.Fe;
-    walk_edges<T>(
-        a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, R, stage, n0, n, lane,
+    float prx = 0.f, pry = 0.f, prz = 0.f, gpl = 0.f;
+    walk_edges<T, SourceRowBwd<CPL>>(
+        a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, stage, n0, n, lane,
         [&](int r) __attribute__((always_inline)) {
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
-            av[j] = ab[r * 2 * H + lane + 64 * j];
-            gar[j] = ag[r * P + lane + 64 * j];
+            av[j] = ab[r * pab + lane + 64 * j];
+            gar[j] = ag[r * px + lane + 64 * j];
             ga_sum[j] = 0.f;
           }
           sc_sum = 0.f;
-          if constexpr (EGNN) { gpx = gp[4 * r]; gpy = gp[4 * r + 1]; gpz = gp[4 * r + 2]; }
+          if constexpr (EGNN) {
+            gpx = gp[4 * r]; gpy = gp[4 * r + 1]; gpz = gp[4 * r + 2];
+            prx = ps[4 * r]; pry = ps[4 * r + 1]; prz = ps[4 * r + 2];
+            gpl = gp[4 * r + (lane < 3 ? lane : 3)];
+          }
         },
-        [&](int r, int s, const float (&ev)[kIslandFeMax]) __attribute__((always_inline)) {
+        [&](int s) __attribute__((always_inline)) {
+          SourceRowBwd<CPL> f;
+#pragma unroll
+          for (int j = 0; j < CPL; ++j) f.b[j] = ab[s * pab + H + lane + 64 * j];
+          f.px = EGNN ? ps[4 * s] : 0.f;
+          f.py = EGNN ? ps[4 * s + 1] : 0.f;
+          f.pz = EGNN ? ps[4 * s + 2] : 0.f;
+          return f;
+        },
+        [&](int r, int s, const float (&ev)[kIslandFeMax], const SourceRowBwd<CPL>& f) __attribute__((always_inline)) {
           float pre[CPL], m[CPL], dot = 0.f;
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
-            pre[j] = (av[j] + ab[s * 2 * H + H + lane + 64 * j]) + ew.term(j, ev, Fe);
+            pre[j] = (av[j] + f.b[j]) + ew.term(j, ev);
             m[j] = fmaxf(pre[j], 0.f);
             if constexpr (EGNN) dot = fmaf(ew.wp[j], m[j], dot);
           }
@@ -674,33 +858,32 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
           if constexpr (EGNN) {
             // pos'[r] += (pos[r] - pos[s]) * sc, sc = w_pos . m: q = d loss / d sc
             const float sc = wave_sum(dot);
-            q = gpx * (ps[4 * r] - ps[4 * s]);
-            q = fmaf(gpy, ps[4 * r + 1] - ps[4 * s + 1], q);
-            q = fmaf(gpz, ps[4 * r + 2] - ps[4 * s + 2], q);
+            q = gpx * (prx - f.px);
+            q = fmaf(gpy, pry - f.py, q);
+            q = fmaf(gpz, prz - f.pz, q);
             sc_sum += sc;
-            if (lane < 3) gq[4 * s + lane] -= gp[4 * r + lane] * sc;
+            if (lane < 3) gq[4 * s + lane] -= gpl * sc;
           }
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
             float g = EGNN ? fmaf(q, ew.wp[j], gar[j]) : gar[j];
             g = pre[j] > 0.f ? g : 0.f;
             ga_sum[j] += g;
-            gz[s * H + lane + 64 * j] += g;
+            gz[s * pz + lane + 64 * j] += g;
             if constexpr (EGNN) gwp[j] = fmaf(q, m[j], gwp[j]);
 #pragma unroll
-            for (int d = 0; d < kIslandFeMax; ++d)
-              if (d < Fe) gwe[j][d] = fmaf(g, ev[d], gwe[j][d]);
+            for (int d = 0; d < kIslandFeMax; ++d) gwe[j][d] = fmaf(g, ev[d], gwe[j][d]);
           }
         },
         [&](int r) __attribute__((always_inline)) {
 #pragma unroll
-          for (int j = 0; j < CPL; ++j) ab[r * 2 * H + lane + 64 * j] = ga_sum[j];   // A[r] is dead: gradient of A[r]
+          for (int j = 0; j < CPL; ++j) ab[r * pab + lane + 64 * j] = ga_sum[j];   // A[r] is dead: gradient of A[r]
           if constexpr (EGNN) {
-            if (lane < 3) gq[4 * r + lane] += gp[4 * r + lane] * (1.f + sc_sum);
+            if (lane < 3) gq[4 * r + lane] += gpl * (1.f + sc_sum);
           }
         });
     wave_sync();
-    for (int i = lane; i < rn * H; i += 64) ab[(i / H) * 2 * H + H + (i & (H - 1))] = gz[i];
+    for (int i = lane; i < kTileRows * H; i += 64) ab[(i / H) * pab + H + (i & (H - 1))] = gz[(i / H) * pz + (i & (H - 1))];
     if constexpr (EGNN)
       for (int i = lane; i < n * 3; i += 64) a.gpos[(int64_t)n0 * 3 + i] = gq[4 * (i / 3) + i % 3];
     wave_sync();
@@ -708,24 +891,27 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
     if (a.gx) {   // gx = gz Wx + [gA | gB] Wn
       const T* wn = static_cast<const T*>(a.w_nodes);
       T* gx = static_cast<T*>(a.gx);
-      for (int kb = 0; kb < F; kb += 128) {
-        int col[2];
-        bool ok[2];
+      const float* const gx_part = a.gx_part;
+      const int64_t ldgx = a.ldgx;
+      for (int col0 = 0; col0 < F; col0 += 64) {
+        f32x16 acc[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { col[j] = kb + lane + 64 * j; ok[j] = col[j] < F; }
-        for (int r0 = 0; r0 < rn; r0 += 8) {
-          float acc[8][2];
+        for (int t = 0; t < 2; ++t) {
+          const int col = col0 + 32 * t + li;
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < 16; ++i) {
+            const int row = acc_row(i, lh);
+            acc[t][i] = (col < F && row < n) ? gx_part[(int64_t)(n0 + row) * F + col] : 0.f;
+          }
+        }
+        mm_w<T, 2>(acc, ab, pab, 2 * H, wn, F, col0, F, li, lh);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-              acc[i][j] = (ok[j] && r0 + i < n) ? a.gx_part[(int64_t)(n0 + r0 + i) * F + col[j]] : 0.f;
-          rows_times_w<T>(acc, ab + r0 * 2 * H, 2 * H, 2 * H, wn, F, col, ok);
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              if (ok[j] && r0 + i < n) gx[(int64_t)(n0 + r0 + i) * a.ldgx + col[j]] = f32_to_scalar<T>(acc[i][j]);
+        for (int t = 0; t < 2; ++t) {
+          const int col = col0 + 32 * t + li;
+          if (col < F)
+            for_acc(acc[t], lh, [&](int row, float v) __attribute__((always_inline)) {
+              if (row < n) gx[(int64_t)(n0 + row) * ldgx + col] = f32_to_scalar<T>(v);
+            });
         }
       }
     }
@@ -743,11 +929,11 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
   ISLAND_PROF(10);
   // gWn = [gA | gB]^T x over the rows of the whole block
   {
-    const int kgroups = (F + 127) / 128;
-    const int tasks = (2 * H / 16) * kgroups;
+    const int ktiles = (F + 31) / 32;
+    const int tasks = (2 * H / 32) * ktiles;
     for (int t = w; t < tasks; t += wpb)
-      block_outer(part + o_wn, F, 16 * (t / kgroups), 128 * (t % kgroups), tiles, wave_floats, nrows, wpb, o_ab, 2 * H, 0, P,
-                  F, 0, lane);
+      block_outer<T, XG>(part + o_wn, F, 32 * (t / ktiles), 32 * (t % ktiles), tiles, wave_floats, nrows, n0s, wpb, o_ab,
+                         pab, 0, px, F, 0, static_cast<const T*>(a.x), a.ldx, li, lh);
   }
   ISLAND_PROF(11);
 }
@@ -802,19 +988,26 @@ __global__ void __launch_bounds__(256) k_island_reduce(IslandReduce a) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-int island_waves_per_block(int rows, int F, int H, bool egnn, bool backward) {
-  const int64_t per_wave = (int64_t)island_wave_floats(rows, F, H, egnn, backward) * 4;
+// Waves (= islands) per block.  The backward keeps the rows of x out of the tile (xg) when that is what lets four
+// waves share a CU's LDS; it needs 4-wide loads of x and an input width that is a multiple of the tile width.
+int island_waves_per_block(int F, int H, int Fe, bool egnn, bool backward, bool xg = false) {
+  const int64_t per_wave = (int64_t)island_wave_floats(F, H, Fe, egnn, backward, xg) * 4;
   const int64_t w = (kIslandLds - kIslandHeader * 4) / per_wave;
   return w > 4 ? 4 : (int)w;
 }
 
-int64_t island_lds_bytes(int rows, int F, int H, bool egnn, bool backward, int wpb) {
-  return kIslandHeader * 4 + (int64_t)island_wave_floats(rows, F, H, egnn, backward) * 4 * wpb;
+bool island_wants_xg(int F, int H, int Fe, bool egnn) {
+  return F % 32 == 0 && island_waves_per_block(F, H, Fe, egnn, true, false) < 4 &&
+         island_waves_per_block(F, H, Fe, egnn, true, true) > island_waves_per_block(F, H, Fe, egnn, true, false);
+}
+
+int64_t island_lds_bytes(int F, int H, int Fe, bool egnn, bool backward, int wpb, bool xg = false) {
+  return kIslandHeader * 4 + (int64_t)island_wave_floats(F, H, Fe, egnn, backward, xg) * 4 * wpb;
 }
 
 template <typename K>
 void allow_lds(K kern, int kernel_id, int64_t bytes) {   // once per kernel and device, with that device current
-  static bool done[64][64];
+  static bool done[128][64];
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !__atomic_load_n(&done[kernel_id][dev], __ATOMIC_ACQUIRE)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kIslandLds) ==
@@ -824,11 +1017,16 @@ void allow_lds(K kern, int kernel_id, int64_t bytes) {   // once per kernel and 
 }
 
 template <typename T, int CPL, bool EGNN, bool VEC>
-void launch_island(const IslandLayer& a, bool backward, int blocks, int wpb, int64_t lds, hipStream_t stream) {
-  const int id = (sizeof(T) == 2) | (CPL == 2) << 1 | EGNN << 2 | VEC << 3 | backward << 4;
-  if (backward) {
-    allow_lds(k_island_bwd<T, CPL, EGNN, VEC>, id, lds);
-    k_island_bwd<T, CPL, EGNN, VEC><<<blocks, 64 * wpb, lds, stream>>>(a);
+void launch_island(const IslandLayer& a, bool backward, bool xg, int blocks, int wpb, int64_t lds, hipStream_t stream) {
+  const int id = (sizeof(T) == 2) | (CPL == 2) << 1 | EGNN << 2 | VEC << 3 | backward << 4 | xg << 5;
+  if (backward && xg) {
+    if constexpr (VEC) {
+      allow_lds(k_island_bwd<T, CPL, EGNN, true, true>, id, lds);
+      k_island_bwd<T, CPL, EGNN, true, true><<<blocks, 64 * wpb, lds, stream>>>(a);
+    }
+  } else if (backward) {
+    allow_lds(k_island_bwd<T, CPL, EGNN, VEC, false>, id, lds);
+    k_island_bwd<T, CPL, EGNN, VEC, false><<<blocks, 64 * wpb, lds, stream>>>(a);
   } else {
     allow_lds(k_island_fwd<T, CPL, EGNN, VEC>, id, lds);
     k_island_fwd<T, CPL, EGNN, VEC><<<blocks, 64 * wpb, lds, stream>>>(a);
@@ -836,10 +1034,10 @@ void launch_island(const IslandLayer& a, bool backward, int blocks, int wpb, int
 }
 
 template <typename T>
-void dispatch_island(const IslandLayer& a, bool egnn, bool vec, bool backward, int blocks, int wpb, int64_t lds,
+void dispatch_island(const IslandLayer& a, bool egnn, bool vec, bool backward, bool xg, int blocks, int wpb, int64_t lds,
                      hipStream_t stream) {
   const bool two = a.H == 128;
-#define MPNN_ISLAND_GO(CPL, EG, VE) launch_island<T, CPL, EG, VE>(a, backward, blocks, wpb, lds, stream)
+#define MPNN_ISLAND_GO(CPL, EG, VE) launch_island<T, CPL, EG, VE>(a, backward, xg, blocks, wpb, lds, stream)
   if (two) {
     if (egnn) vec ? MPNN_ISLAND_GO(2, true, true) : MPNN_ISLAND_GO(2, true, false);
     else vec ? MPNN_ISLAND_GO(2, false, true) : MPNN_ISLAND_GO(2, false, false);
@@ -857,10 +1055,10 @@ int32_t check_layer(const mpnn_island_layer* d, bool backward, const char* who) 
   if (d->F < 1 || d->Fe < 1 || d->Fe > kIslandFeMax) return fail(MPNN_E_INVALID, "%s: needs F >= 1 and 1 <= Fe <= 8", who);
   if (d->num_nodes < 0 || d->num_nodes > INT32_MAX || d->n_islands < 0 || d->tail_units < 0)
     return fail(MPNN_E_INVALID, "%s: bad sizes", who);
-  if (d->rows < 8 || d->rows % 8) return fail(MPNN_E_INVALID, "%s: rows must be a positive multiple of 8", who);
+  if (d->rows != kTileRows) return fail(MPNN_E_INVALID, "%s: rows must be %d (the height of a tile)", who, kTileRows);
   const bool egnn = d->pos != nullptr;
-  if (island_waves_per_block(d->rows, d->F, d->H, egnn, backward) < 1)
-    return fail(MPNN_E_CAPACITY, "%s: a tile of %d rows (F %d, H %d) does not fit the LDS", who, d->rows, d->F, d->H);
+  if (island_waves_per_block(d->F, d->H, d->Fe, egnn, backward) < 1)
+    return fail(MPNN_E_CAPACITY, "%s: a tile for F %d, H %d does not fit the LDS", who, d->F, d->H);
   if (d->n_islands + d->tail_units == 0) return MPNN_OK;
   if (!d->rowptr || !d->col || !d->island_ptr || !d->x || !d->ea || !d->w_nodes || !d->w_edge || !d->w_out || !d->y)
     return fail(MPNN_E_INVALID, "%s: null pointer argument", who);
@@ -909,7 +1107,7 @@ extern "C" {
 
 int64_t mpnn_islands_workspace_bytes(int64_t num_nodes) {
   if (num_nodes < 0 || num_nodes > INT32_MAX) return -1;
-  return align_up((num_nodes + 1) * 4, 256);
+  return 2 * align_up((num_nodes + 1) * 4, 256);
 }
 
 int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t* island_ptr,
@@ -918,23 +1116,37 @@ int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t nu
   if (!rowptr || !island_ptr || !meta || !workspace) return fail(MPNN_E_INVALID, "mpnn_islands_build: null pointer argument");
   if (workspace_bytes < mpnn_islands_workspace_bytes(num_nodes))
     return fail(MPNN_E_CAPACITY, "mpnn_islands_build: workspace too small");
-  k_islands_build<<<1, kScanBlock, 0, stream>>>(rowptr, col, (int)num_nodes, island_ptr, meta, static_cast<int32_t*>(workspace));
+  int32_t* lo = static_cast<int32_t*>(workspace);
+  int32_t* hi = lo + align_up((num_nodes + 1) * 4, 256) / 4;
+  if (num_nodes > 0) {
+    int64_t blocks = (num_nodes + 255) / 256;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    k_island_bounds<<<(int)blocks, 256, 0, stream>>>(rowptr, col, (int)num_nodes, lo, hi);
+    MPNN_LAUNCH_CHECK("k_island_bounds");
+  }
+  k_islands_build<<<1, kScanBlock, 0, stream>>>(rowptr, (int)num_nodes, lo, hi, island_ptr, meta);
   MPNN_LAUNCH_CHECK("k_islands_build");
   return MPNN_OK;
 }
 
-int32_t mpnn_island_layer_waves(int32_t rows, int32_t F, int32_t H, int32_t egnn, int32_t backward) {
-  if (rows < 8 || rows % 8 || F < 1 || (H != 64 && H != 128)) return 0;
-  const int w = island_waves_per_block(rows, F, H, egnn != 0, backward != 0);
+int32_t mpnn_island_layer_waves(int32_t F, int32_t H, int32_t Fe, int32_t egnn, int32_t backward) {
+  if (F < 1 || (H != 64 && H != 128) || Fe < 1 || Fe > kIslandFeMax) return 0;
+  const int w = island_waves_per_block(F, H, Fe, egnn != 0, backward != 0);
   return w < 0 ? 0 : w;
 }
 
-int64_t mpnn_island_layer_partial_floats(int32_t n_islands, int32_t tail_units, int32_t rows, int32_t F, int32_t H,
-                                         int32_t Fe, int32_t egnn) {
-  const int wpb = mpnn_island_layer_waves(rows, F, H, egnn, 1);
-  if (wpb < 1 || n_islands < 0 || tail_units < 0 || Fe < 1 || Fe > kIslandFeMax) return -1;
-  const int64_t blocks = ((int64_t)n_islands + tail_units + wpb - 1) / wpb;
-  return blocks * island_partial_floats(F, H, Fe, wpb, egnn != 0);
+int64_t mpnn_island_layer_partial_floats(int32_t n_islands, int32_t tail_units, int32_t F, int32_t H, int32_t Fe,
+                                         int32_t egnn) {
+  if (F < 1 || (H != 64 && H != 128) || n_islands < 0 || tail_units < 0 || Fe < 1 || Fe > kIslandFeMax) return -1;
+  int64_t most = -1;
+  for (int xg = 0; xg < 2; ++xg) {   // which form runs depends on the alignment of x: room for either
+    const int wpb = island_waves_per_block(F, H, Fe, egnn != 0, true, xg != 0);
+    if (wpb < 1) continue;
+    const int64_t blocks = ((int64_t)n_islands + tail_units + wpb - 1) / wpb;
+    const int64_t v = blocks * island_partial_floats(F, H, Fe, wpb, egnn != 0);
+    if (v > most) most = v;
+  }
+  return most;
 }
 
 int32_t mpnn_island_layer_fwd(const mpnn_island_layer* d, mpnn_stream_t stream) {
@@ -942,12 +1154,12 @@ int32_t mpnn_island_layer_fwd(const mpnn_island_layer* d, mpnn_stream_t stream) 
   const int units = d->n_islands + d->tail_units;
   if (units == 0) return MPNN_OK;
   const bool egnn = d->pos != nullptr;
-  const int wpb = island_waves_per_block(d->rows, d->F, d->H, egnn, false);
+  const int wpb = island_waves_per_block(d->F, d->H, d->Fe, egnn, false);
   const int blocks = (units + wpb - 1) / wpb;
-  const int64_t lds = island_lds_bytes(d->rows, d->F, d->H, egnn, false, wpb);
+  const int64_t lds = island_lds_bytes(d->F, d->H, d->Fe, egnn, false, wpb);
   const IslandLayer a = to_args(d);
-  if (d->dtype == MPNN_F32) dispatch_island<float>(a, egnn, island_vec(d), false, blocks, wpb, lds, stream);
-  else dispatch_island<bf16_t>(a, egnn, island_vec(d), false, blocks, wpb, lds, stream);
+  if (d->dtype == MPNN_F32) dispatch_island<float>(a, egnn, island_vec(d), false, false, blocks, wpb, lds, stream);
+  else dispatch_island<bf16_t>(a, egnn, island_vec(d), false, false, blocks, wpb, lds, stream);
   MPNN_LAUNCH_CHECK("k_island_fwd");
   return MPNN_OK;
 }
@@ -956,14 +1168,18 @@ int32_t mpnn_island_layer_bwd(const mpnn_island_layer* d, mpnn_stream_t stream) 
   if (int32_t rc = check_layer(d, true, "mpnn_island_layer_bwd")) return rc;
   const bool egnn = d->pos != nullptr;
   const int units = d->n_islands + d->tail_units;
-  const int wpb = island_waves_per_block(d->rows, d->F, d->H, egnn, true);
+  const bool vec = island_vec(d);
+  // 4-wide loads of x itself (the forward copies it into the tile element by element when it must)
+  const bool x_vec = vec && ((uintptr_t)d->x & 15) == 0 && d->ldx % 4 == 0;
+  const bool xg = x_vec && island_wants_xg(d->F, d->H, d->Fe, egnn);
+  const int wpb = island_waves_per_block(d->F, d->H, d->Fe, egnn, true, xg);
   const int blocks = (units + wpb - 1) / wpb;
   IslandLayer a = to_args(d);
   a.partial_stride = island_partial_floats(d->F, d->H, d->Fe, wpb, egnn);
   if (units > 0) {
-    const int64_t lds = island_lds_bytes(d->rows, d->F, d->H, egnn, true, wpb);
-    if (d->dtype == MPNN_F32) dispatch_island<float>(a, egnn, island_vec(d), true, blocks, wpb, lds, stream);
-    else dispatch_island<bf16_t>(a, egnn, island_vec(d), true, blocks, wpb, lds, stream);
+    const int64_t lds = island_lds_bytes(d->F, d->H, d->Fe, egnn, true, wpb, xg);
+    if (d->dtype == MPNN_F32) dispatch_island<float>(a, egnn, vec, true, xg, blocks, wpb, lds, stream);
+    else dispatch_island<bf16_t>(a, egnn, vec, true, xg, blocks, wpb, lds, stream);
     MPNN_LAUNCH_CHECK("k_island_bwd");
   }
   IslandReduce r{d->partial, a.partial_stride, d->island_ptr, d->num_nodes, d->n_islands, d->tail_units, d->rows,

@@ -28,10 +28,10 @@ ITEM_ORDER_MIN_EDGES = 1 << 22
 
 
 # Graphs of at most this many nodes are searched for islands when their structure is built (one more launch of
-# the build, its result read back with the item counts); see Islands.  MPNN_AMD_ISLANDS=1 switches the search and
-# with it the one-launch layers on.
-ISLAND_SEARCH_MAX_NODES = 1 << 16
-ISLANDS_ENABLED = os.environ.get("MPNN_AMD_ISLANDS", "0") == "1"
+# the build, its result read back with the item counts); see Islands.  MPNN_AMD_ISLANDS=0 switches the search and
+# with it the one-launch layers off.
+ISLAND_SEARCH_MAX_NODES = 1 << 18
+ISLANDS_ENABLED = os.environ.get("MPNN_AMD_ISLANDS", "1") != "0"
 
 
 class Islands:

@@ -257,6 +257,25 @@ def halo_row_lists(edge_index: torch.Tensor, bounds: list, rank: int):
     return out
 
 
+def islands(edge_index: torch.Tensor, num_nodes: int) -> list:
+    """Finest split of the node range into runs of consecutive ids that no edge leaves: the cut after node r stands
+    iff no edge has one end <= r and the other > r.  Returns the run boundaries [0, ..., num_nodes].  (The graphs
+    of a PyG mini-batch, data/dataset.py:94-96, are unions of such runs; the engine's whole-layer kernels for
+    small graphs work run by run.)"""
+    lo = torch.minimum(edge_index[0], edge_index[1]).tolist()
+    hi = torch.maximum(edge_index[0], edge_index[1]).tolist()
+    spans = [0] * (num_nodes + 1)          # spans[r] = edges over the cut after r, as a difference array
+    for a, b in zip(lo, hi):
+        spans[a] += 1
+        spans[b] -= 1
+    out, open_edges = [0], 0
+    for r in range(num_nodes):
+        open_edges += spans[r]
+        if open_edges == 0:
+            out.append(r + 1)
+    return out
+
+
 # ----------------------------------------------------------------------------
 # EGNN coordinate update (no reference counterpart)
 # ----------------------------------------------------------------------------

@@ -201,3 +201,18 @@ def test_rows_in_item_order_on_the_device_are_bit_exact(n, e, chunk, power):
             MPGraph(bad, n, chunk=chunk, row_order="items")
         else:
             raise IndexError
+
+
+def test_islands_oracle_against_brute_force():
+    """O.islands (the specification the device search is compared with) against the definition itself: a cut after
+    node r stands iff no edge has its ends on both sides."""
+    g = torch.Generator().manual_seed(0)
+    for _ in range(60):
+        n = int(torch.randint(1, 40, (1,), generator=g))
+        e = int(torch.randint(0, 30, (1,), generator=g))
+        far = torch.randint(0, n, (2, e), generator=g)
+        near = far.clone()
+        near[1] = (near[0] + torch.randint(-2, 3, (e,), generator=g)).clamp(0, n - 1)
+        for ei in (far, near):
+            want = [0] + [r + 1 for r in range(n) if not any(min(a, b) <= r < max(a, b) for a, b in ei.t().tolist())]
+            assert O.islands(ei, n) == want
