@@ -26,6 +26,7 @@ constexpr int kIslandLds = 160 * 1024;   // LDS of one CU
 constexpr int kIslandHeader = 16;        // floats in front of the tiles: rows held by each wave of the block
 constexpr int kIslandFeMax = 8;
 constexpr int kScanBlock = 1024;
+constexpr int kRowsInRegisters = 32;   // island search: rows per thread that can stay in registers
 
 // ---------------------------------------------------------------------------------------------------------------
 // structure: the islands of a destination-sorted CSR
@@ -77,42 +78,93 @@ __global__ void __launch_bounds__(kScanBlock) k_islands_build(const int32_t* __r
   auto imax = [](int a, int b) { return a > b ? a : b; };
   auto iadd = [](int a, int b) { return a + b; };
   if (t == 0) { max_nodes = 0; max_edges = 0; island_ptr[0] = 0; }
-  // suffix minimum of lo over the rows AFTER r: the thread's own rows from the back, then the later threads' totals
-  int mine = INT_MAX;
-  for (int r = r0; r < r1; ++r) mine = imin(mine, lo[r]);
-  // a scan over the threads in reverse order = a forward scan of the mirrored values
   __shared__ int totals[kScanBlock];
-  totals[kScanBlock - 1 - t] = mine;
-  __syncthreads();
-  const int mirrored = block_scan_inclusive(totals[t], sm, imin);   // min over threads >= (1023 - t)
-  totals[t] = mirrored;
-  __syncthreads();
-  int after = t + 1 < kScanBlock ? totals[kScanBlock - 2 - t] : INT_MAX;   // min over threads > t
-  __syncthreads();
-  for (int r = r1 - 1; r >= r0; --r) {
-    const int v = lo[r];
-    lo[r] = after;
-    after = imin(after, v);
-  }
-  // prefix maximum of hi up to and including r
-  int top = -1;
-  for (int r = r0; r < r1; ++r) top = imax(top, hi[r]);
-  const int incl = block_scan_inclusive(top, sm, imax);
-  totals[t] = incl;
-  __syncthreads();
-  int before = t > 0 ? totals[t - 1] : -1;   // max over threads < t
-  __syncthreads();
-  int cuts = 0;
-  for (int r = r0; r < r1; ++r) {
-    before = imax(before, hi[r]);
-    cuts += (before <= r && lo[r] > r) ? 1 : 0;
-  }
-  const int upto = block_scan_inclusive(cuts, sm, iadd);
-  int pos = upto - cuts;   // cuts of the threads before this one
-  before = t > 0 ? totals[t - 1] : -1;
-  for (int r = r0; r < r1; ++r) {
-    before = imax(before, hi[r]);
-    if (before <= r && lo[r] > r) island_ptr[++pos] = r + 1;
+  int upto;
+  if (k <= kRowsInRegisters) {
+    // the thread's rows live in registers: one round of loads, everything after it is arithmetic
+    int vlo[kRowsInRegisters], vhi[kRowsInRegisters];
+#pragma unroll
+    for (int i = 0; i < kRowsInRegisters; ++i) {
+      const bool ok = r0 + i < r1;
+      const int r = ok ? r0 + i : (n > 0 ? n - 1 : 0);
+      const int a = n > 0 ? lo[r] : 0, b2 = n > 0 ? hi[r] : 0;
+      vlo[i] = ok ? a : INT_MAX;
+      vhi[i] = ok ? b2 : -1;
+    }
+    int mine = INT_MAX, top = -1;
+#pragma unroll
+    for (int i = 0; i < kRowsInRegisters; ++i) { mine = imin(mine, vlo[i]); top = imax(top, vhi[i]); }
+    totals[kScanBlock - 1 - t] = mine;   // a scan over the threads in reverse order = a forward scan of the mirror
+    __syncthreads();
+    const int mirrored = block_scan_inclusive(totals[t], sm, imin);
+    totals[t] = mirrored;
+    __syncthreads();
+    int after = t + 1 < kScanBlock ? totals[kScanBlock - 2 - t] : INT_MAX;   // min over the threads after t
+    __syncthreads();
+#pragma unroll
+    for (int i = kRowsInRegisters - 1; i >= 0; --i) {   // vlo[i] <- minimum over the rows after r0 + i
+      const int v = vlo[i];
+      vlo[i] = after;
+      after = imin(after, v);
+    }
+    const int incl = block_scan_inclusive(top, sm, imax);
+    totals[t] = incl;
+    __syncthreads();
+    int before = t > 0 ? totals[t - 1] : -1;   // max over the threads before t
+    __syncthreads();
+    int cuts = 0;
+    unsigned cut_bits = 0;
+#pragma unroll
+    for (int i = 0; i < kRowsInRegisters; ++i) {
+      before = imax(before, vhi[i]);
+      const bool cut = r0 + i < r1 && before <= r0 + i && vlo[i] > r0 + i;
+      cuts += cut ? 1 : 0;
+      cut_bits |= cut ? 1u << i : 0u;
+    }
+    upto = block_scan_inclusive(cuts, sm, iadd);
+    int pos = upto - cuts;
+#pragma unroll
+    for (int i = 0; i < kRowsInRegisters; ++i)
+      if (cut_bits >> i & 1u) island_ptr[++pos] = r0 + i + 1;
+  } else {
+    // suffix minimum of lo over the rows AFTER r: the thread's own rows from the back, then the later threads' totals
+    int mine = INT_MAX;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) mine = imin(mine, lo[r]);
+    // a scan over the threads in reverse order = a forward scan of the mirrored values
+    totals[kScanBlock - 1 - t] = mine;
+    __syncthreads();
+    const int mirrored = block_scan_inclusive(totals[t], sm, imin);   // min over threads >= (1023 - t)
+    totals[t] = mirrored;
+    __syncthreads();
+    int after = t + 1 < kScanBlock ? totals[kScanBlock - 2 - t] : INT_MAX;   // min over threads > t
+    __syncthreads();
+    for (int r = r1 - 1; r >= r0; --r) {
+      const int v = lo[r];
+      lo[r] = after;
+      after = imin(after, v);
+    }
+    // prefix maximum of hi up to and including r
+    int top = -1;
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) top = imax(top, hi[r]);
+    const int incl = block_scan_inclusive(top, sm, imax);
+    totals[t] = incl;
+    __syncthreads();
+    int before = t > 0 ? totals[t - 1] : -1;   // max over threads < t
+    __syncthreads();
+    int cuts = 0;
+    for (int r = r0; r < r1; ++r) {
+      before = imax(before, hi[r]);
+      cuts += (before <= r && lo[r] > r) ? 1 : 0;
+    }
+    upto = block_scan_inclusive(cuts, sm, iadd);
+    int pos = upto - cuts;   // cuts of the threads before this one
+    before = t > 0 ? totals[t - 1] : -1;
+    for (int r = r0; r < r1; ++r) {
+      before = imax(before, hi[r]);
+      if (before <= r && lo[r] > r) island_ptr[++pos] = r + 1;
+    }
   }
   totals[t] = upto;
   __syncthreads();
@@ -675,9 +727,9 @@ __global__ void __launch_bounds__(256) k_island_fwd(IslandLayer a) {
   ISLAND_PROF(4);
 }
 
-// Partial weight gradients of one block: [gW_out H x (F+H)] [gWn 2H x F] [gWe wpb x H x Fe] [g w_pos wpb x H].
-__host__ __device__ inline int64_t island_partial_floats(int F, int H, int Fe, int wpb, bool egnn) {
-  const int64_t v = (int64_t)H * (F + H) + (int64_t)2 * H * F + (int64_t)wpb * H * Fe + (egnn ? (int64_t)wpb * H : 0);
+// Partial weight gradients of one block: [gW_out H x (F+H)] [gWn 2H x F] [gWe H x Fe] [g w_pos H].
+__host__ __device__ inline int64_t island_partial_floats(int F, int H, int Fe, bool egnn) {
+  const int64_t v = (int64_t)H * (F + H) + (int64_t)2 * H * F + (int64_t)H * Fe + (egnn ? H : 0);
   return (v + 63) / 64 * 64;
 }
 
@@ -705,7 +757,7 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
   float* gp = ps + 4 * kTileRows;
   float* gq = gp + 4 * kTileRows;
   float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
-  const int64_t o_wn = (int64_t)H * (F + H), o_we = o_wn + (int64_t)2 * H * F, o_wp = o_we + (int64_t)wpb * H * a.Fe;
+  const int64_t o_wn = (int64_t)H * (F + H), o_we = o_wn + (int64_t)2 * H * F;   // g w_pos follows gWe
 
   if ((int)blockIdx.x * wpb >= island_active_units(a.island_ptr, a.n_islands, a.tail_units, kTileRows, a.N)) return;   // whole block
   const Unit un = island_unit(a, blockIdx.x * wpb + w);
@@ -917,15 +969,21 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
     }
   }
   ISLAND_PROF(9);
-  // the lane's rows of gWe and g w_pos: one slot per wave
+  // the lane's rows of gWe and g w_pos go through the (now dead) gz slab of its wave, and the block adds the waves'
+  // shares in wave order
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
 #pragma unroll
     for (int d = 0; d < kIslandFeMax; ++d)
-      if (d < a.Fe) part[o_we + ((int64_t)w * H + lane + 64 * j) * a.Fe + d] = gwe[j][d];
-    if constexpr (EGNN) part[o_wp + (int64_t)w * H + lane + 64 * j] = gwp[j];
+      if (d < a.Fe) gz[(lane + 64 * j) * a.Fe + d] = gwe[j][d];
+    if constexpr (EGNN) gz[H * a.Fe + lane + 64 * j] = gwp[j];
   }
   __syncthreads();
+  for (int e = threadIdx.x; e < H * a.Fe + (EGNN ? H : 0); e += blockDim.x) {
+    float t = 0.f;
+    for (int w2 = 0; w2 < wpb; ++w2) t += tiles[w2 * wave_floats + o_gz + e];
+    part[o_we + e] = t;
+  }
   ISLAND_PROF(10);
   // gWn = [gA | gB]^T x over the rows of the whole block
   {
@@ -938,8 +996,8 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
   ISLAND_PROF(11);
 }
 
-// Sums the blocks' partials in a fixed order: 16 lanes per element take every 16th partial in ascending order, then
-// lane group 0 adds the 16 sums in ascending order.
+// Sums the blocks' partials in a fixed order: a thread takes one element and every fourth block in ascending order
+// (eight loads in flight), then the four sums of an element are added in ascending order.
 struct IslandReduce {
   const float* partial; int64_t stride; const int32_t* island_ptr; int64_t N; int32_t n_islands, tail_units, rows;
   int32_t wpb, F, H, Fe, egnn;
@@ -948,40 +1006,30 @@ struct IslandReduce {
 
 template <typename T>
 __global__ void __launch_bounds__(256) k_island_reduce(IslandReduce a) {
-  __shared__ float sm[16][17];
-  const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+  __shared__ float sm[4][64];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t n1 = (int64_t)a.H * (a.F + a.H), n2 = (int64_t)2 * a.H * a.F, n3 = (int64_t)a.H * a.Fe;
   const int64_t total = n1 + n2 + n3 + (a.egnn ? a.H : 0);
-  const int64_t e = (int64_t)blockIdx.x * 16 + el;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el;
   float s = 0.f;
-  T* dst = nullptr;
   if (e < total) {
-    int64_t off, slot_stride = 0;
-    int slots = 1;
-    if (e < n1) { off = e; dst = a.g_wout ? static_cast<T*>(a.g_wout) + e : nullptr; }
-    else if (e < n1 + n2) { off = e; dst = a.g_wn ? static_cast<T*>(a.g_wn) + (e - n1) : nullptr; }
-    else if (e < n1 + n2 + n3) {
-      off = e; slots = a.wpb; slot_stride = n3;
-      dst = a.g_we ? static_cast<T*>(a.g_we) + (e - n1 - n2) : nullptr;
-    } else {
-      off = n1 + n2 + (int64_t)a.wpb * n3 + (e - n1 - n2 - n3); slots = a.wpb; slot_stride = a.H;
-      dst = a.g_wp ? static_cast<T*>(a.g_wp) + (e - n1 - n2 - n3) : nullptr;
-    }
-    if (dst) {
-      const int units = (a.n_islands + a.tail_units) > 0
-                            ? island_active_units(a.island_ptr, a.n_islands, a.tail_units, a.rows, a.N) : 0;
-      const int64_t slabs = (int64_t)((units + a.wpb - 1) / a.wpb) * slots;   // the blocks that wrote a partial
-      for (int64_t i = g; i < slabs; i += 16)
-        s += a.partial[(i / slots) * a.stride + off + (i % slots) * slot_stride];
-    }
+    const int units = (a.n_islands + a.tail_units) > 0
+                          ? island_active_units(a.island_ptr, a.n_islands, a.tail_units, a.rows, a.N) : 0;
+    const int blocks = (units + a.wpb - 1) / a.wpb;   // the blocks that wrote a partial
+    const float* p = a.partial + e;
+#pragma unroll 8
+    for (int b = g; b < blocks; b += 4) s += p[(int64_t)b * a.stride];
   }
   sm[g][el] = s;
   __syncthreads();
-  if (g == 0 && dst) {
-    float t = sm[0][el];
-#pragma unroll
-    for (int i = 1; i < 16; ++i) t += sm[i][el];
-    *dst = f32_to_scalar<T>(t);
+  if (g == 0 && e < total) {
+    const float t = ((sm[0][el] + sm[1][el]) + sm[2][el]) + sm[3][el];
+    T* dst;
+    if (e < n1) dst = a.g_wout ? static_cast<T*>(a.g_wout) + e : nullptr;
+    else if (e < n1 + n2) dst = a.g_wn ? static_cast<T*>(a.g_wn) + (e - n1) : nullptr;
+    else if (e < n1 + n2 + n3) dst = a.g_we ? static_cast<T*>(a.g_we) + (e - n1 - n2) : nullptr;
+    else dst = a.g_wp ? static_cast<T*>(a.g_wp) + (e - n1 - n2 - n3) : nullptr;
+    if (dst) *dst = f32_to_scalar<T>(t);
   }
 }
 
@@ -1143,7 +1191,7 @@ int64_t mpnn_island_layer_partial_floats(int32_t n_islands, int32_t tail_units, 
     const int wpb = island_waves_per_block(F, H, Fe, egnn != 0, true, xg != 0);
     if (wpb < 1) continue;
     const int64_t blocks = ((int64_t)n_islands + tail_units + wpb - 1) / wpb;
-    const int64_t v = blocks * island_partial_floats(F, H, Fe, wpb, egnn != 0);
+    const int64_t v = blocks * island_partial_floats(F, H, Fe, egnn != 0);
     if (v > most) most = v;
   }
   return most;
@@ -1175,7 +1223,7 @@ int32_t mpnn_island_layer_bwd(const mpnn_island_layer* d, mpnn_stream_t stream) 
   const int wpb = island_waves_per_block(d->F, d->H, d->Fe, egnn, true, xg);
   const int blocks = (units + wpb - 1) / wpb;
   IslandLayer a = to_args(d);
-  a.partial_stride = island_partial_floats(d->F, d->H, d->Fe, wpb, egnn);
+  a.partial_stride = island_partial_floats(d->F, d->H, d->Fe, egnn);
   if (units > 0) {
     const int64_t lds = island_lds_bytes(d->F, d->H, d->Fe, egnn, true, wpb, xg);
     if (d->dtype == MPNN_F32) dispatch_island<float>(a, egnn, vec, true, xg, blocks, wpb, lds, stream);
@@ -1185,7 +1233,7 @@ int32_t mpnn_island_layer_bwd(const mpnn_island_layer* d, mpnn_stream_t stream) 
   IslandReduce r{d->partial, a.partial_stride, d->island_ptr, d->num_nodes, d->n_islands, d->tail_units, d->rows,
                  wpb, d->F, d->H, d->Fe, egnn ? 1 : 0, d->g_wout, d->g_wn, d->g_we, d->g_wpos};
   const int64_t total = (int64_t)d->H * (d->F + d->H) + (int64_t)2 * d->H * d->F + (int64_t)d->H * d->Fe + (egnn ? d->H : 0);
-  const int rblocks = (int)((total + 15) / 16);
+  const int rblocks = (int)((total + 63) / 64);
   if (d->dtype == MPNN_F32) k_island_reduce<float><<<rblocks, 256, 0, stream>>>(r);
   else k_island_reduce<bf16_t><<<rblocks, 256, 0, stream>>>(r);
   MPNN_LAUNCH_CHECK("k_island_reduce");

@@ -17,6 +17,13 @@ echo "== powerlaw bf16 kernel trace"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_powerlaw_bf16 -o powerlaw --output-format csv -- \
     python3 bench.py --dtype bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-model-step > $O/${R}_bench_powerlaw_bf16.json 2> gpurun_out/prof_powerlaw_bf16.err || exit 1
 cp gpurun_out/prof_powerlaw_bf16/powerlaw_kernel_stats.csv $O/${R}_bench_powerlaw_bf16_kernel_stats.csv || exit 1
+echo "== qm9 / modelnet EGNN kernel traces"
+for SPEC in "qm9 bf16" "modelnet f32"; do
+  set -- $SPEC
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_egnn_$1 -o $1 --output-format csv -- \
+      python3 bench.py --workload $1 --layer egnn --dtype $2 --steps 10 --warmup 3 --no-cpu-baseline --no-verify --no-model-step > $O/${R}_bench_$1_egnn_$2.json 2> gpurun_out/prof_egnn_$1.err || exit 1
+  cp gpurun_out/prof_egnn_$1/$1_kernel_stats.csv $O/${R}_bench_$1_egnn_$2_kernel_stats.csv || exit 1
+done
 SPECS=""
 for W in powerlaw flickr; do
   for C in FETCH_SIZE WRITE_SIZE; do
