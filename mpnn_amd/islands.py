@@ -34,14 +34,21 @@ def plan_for(graph: MPGraph, f: int, h: int, fe: int, egnn: bool) -> Plan | None
     """The tile shape for this layer on this graph, or None when the island kernels do not apply (no islands known,
     islands too large or too many, widths outside the kernels' range)."""
     isl = getattr(graph, "islands", None)
-    if isl is None or isl.count == 0 or isl.count > COUNT_MAX:
+    if isl is None:
+        return None
+    key = (f, h, fe, egnn, COUNT_MAX)
+    plans = graph._scratch.setdefault("island_plans", {})    # per graph: the answer depends on the shapes only
+    if key not in plans:
+        plans[key] = _plan(isl, f, h, fe, egnn)
+    return plans[key]
+
+
+def _plan(isl, f: int, h: int, fe: int, egnn: bool) -> Plan | None:
+    if isl.count == 0 or isl.count > COUNT_MAX or isl.max_nodes > ROWS:
         return None
     if h not in (64, 128) or not 1 <= fe <= 8 or f < 1:
         return None
-    if isl.max_nodes > ROWS:
-        return None
-    lib = _lib.load()
-    if lib.mpnn_island_layer_waves(f, h, fe, int(egnn), 1) < 1:
+    if _lib.load().mpnn_island_layer_waves(f, h, fe, int(egnn), 1) < 1:
         return None
     return Plan(ROWS, (isl.tail_rows + ROWS - 1) // ROWS, egnn)
 

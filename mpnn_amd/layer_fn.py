@@ -106,6 +106,13 @@ class _LayerFn(torch.autograd.Function):
     def forward(ctx, x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
         want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
         x = x if x.is_contiguous() else x.contiguous()
+        ctx.plan = islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), False)
+        if ctx.plan is not None:   # the whole layer in one launch; the backward recomputes the intermediates
+            y, _, saved = islands.forward(ctx.plan, graph, x, edge_attr, w_nodes, w_edge, w_out)
+            if want:
+                ctx.save_for_backward(y, *saved[:5])
+                ctx.graph = graph
+            return y
         y, ab, aggr, cnt, maskbits, ea_t = forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, want)
         if want:
             ctx.save_for_backward(x, ab, aggr, cnt[0], cnt[1], maskbits, y, ea_t, w_nodes, w_edge, w_out)
@@ -114,8 +121,12 @@ class _LayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
-        x, ab, aggr, cnt8, cnt_big, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
         needs = tuple(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
+        if ctx.plan is not None:
+            y, *saved = ctx.saved_tensors
+            gx, g_wn, g_we, g_wout = islands.backward(ctx.plan, ctx.graph, gy, y, tuple(saved) + (None, None), needs)[:4]
+            return gx, None, g_wn, g_we, g_wout, None
+        x, ab, aggr, cnt8, cnt_big, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
         gx, g_wn, g_we, g_wout = backward_impl(gy, x, ab, aggr, (cnt8, cnt_big), maskbits, y, ea_t, w_nodes, w_edge, w_out,
                                                ctx.graph, needs)
         return gx, None, g_wn, g_we, g_wout, None
