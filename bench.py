@@ -96,6 +96,19 @@ def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0, f=0):
     raise ValueError(kind)
 
 
+F32_MATRIX_PEAK_TFLOPS = 157.3   # v_mfma_f32_32x32x2f32, the instruction of the island kernels' dense products
+
+
+def island_flops(kind, n_rows, e, f, h, fe):
+    """Algorithmic floating-point operations of one launch of the whole-layer kernels (real rows and edges, not the
+    32-row tiles they are padded to): forward = projection + messages + update; backward = the projection and the
+    messages again, gz W_out, the two weight-gradient products, [gA | gB] Wn and the backward edge pass."""
+    proj, upd, edge = 2 * n_rows * 2 * h * f, 2 * n_rows * h * (f + h), e * h * (2 * fe + 3)
+    if kind == "island_layer_fwd":
+        return proj + upd + edge
+    return (proj + edge) + 2 * upd + 2 * proj + e * h * (2 * fe + 3 + 2 * fe + 2)
+
+
 def pmc_traffic(workload, dtype, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate FETCH_SIZE / WRITE_SIZE
     runs of this script, corrected for gfx950 as profiles/*_pmc_traffic.json records), or None."""
@@ -536,6 +549,17 @@ def main():
         traffic = traffic_src = None
         if world == 1 and args.scale == 1.0 and args.mode == "sum":
             traffic, traffic_src = pmc_traffic(args.workload, args.dtype, dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src}
+        if dom.startswith("island_layer"):
+            # a batch of small graphs runs as whole-layer kernels whose tiles never leave the LDS: their bytes are a
+            # few megabytes and the limit is the fp32 matrix pipe (and, at this size, launch latency)
+            tf = island_flops(dom, rows[dom], e_local, F_in, H, Fe) / kavg[dom] / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": F32_MATRIX_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": tf / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                        "note": "algorithmic flops of the real rows and edges; the island_layer_bwd span includes "
+                                "the 5 us reduction of the weight-gradient partials"}
         mp_time = sum(kavg.values())
         model_bytes = layer_bytes_model(n_rows_fwd, e_local, H, Fe, s)
         result = {
@@ -558,9 +582,7 @@ def main():
                             else f"dst-range partition x{world} + halo exchange ({exchange['mode']})")
                            + f" ({dist.get_backend()} reports {dist.get_world_size()} ranks)"),
                        "launch": "HIP graph replay" if run_step is not step else "eager"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src},
+            "roofline": roofline,
             "kernels": per_kernel,
             "message_passing_only": {
                 "ms": mp_time * 1e3, "edges_per_sec": e_local / mp_time,
