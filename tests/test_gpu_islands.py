@@ -149,6 +149,9 @@ CASES = [
     pytest.param("sum", torch.float32, 64, 128, 4, True, id="egnn-f32-64-128"),
     pytest.param("sum", torch.bfloat16, 64, 64, 4, True, id="egnn-bf16-64-64"),
     pytest.param("sum", torch.bfloat16, 11, 64, 4, True, id="egnn-bf16-11-64"),
+    pytest.param("sum", torch.float32, 128, 128, 4, False, id="sum-f32-128-128"),
+    pytest.param("sum", torch.bfloat16, 128, 128, 2, True, id="egnn-bf16-128-128"),
+    pytest.param("sum", torch.float32, 32, 64, 4, True, id="egnn-f32-32-64"),
 ]
 
 
@@ -177,6 +180,43 @@ def test_island_layer_outputs_and_every_gradient(islands_on, mode, dtype, f, h, 
     assert all(torch.equal(grads2[k], grads[k]) for k in grads)
     if egnn:
         assert torch.equal(pos2, got_pos) and torch.equal(gpos2, gpos)
+
+
+@pytest.mark.parametrize("egnn", [False, True], ids=["mpnn", "egnn"])
+def test_islands_with_many_edges(islands_on, egnn):
+    """Dense little graphs (up to n^2 edges, repeated edges and self loops included): the edge walk stages 32 edges
+    at a time, so islands of several hundred edges cross many staging rounds and rows end inside them."""
+    from mpnn_amd import EGNNLayer, MPNNLayerSum, islands
+    from mpnn_amd.graph import graph_for
+    d = molecules(11, 60, max_nodes=24, dense=True)
+    assert d["edge_index"].size(1) > 60 * 40
+    f, h, fe = 11, 64, 4
+    x, ea, pos, ei = d["x"], d["edge_attr"], d["pos"], d["edge_index"]
+    torch.manual_seed(1)
+    layer = (EGNNLayer if egnn else MPNNLayerSum)(f, fe, h)
+    params = {k: v.detach().clone().double().requires_grad_(True) for k, v in layer.state_dict().items()}
+    gen = torch.Generator().manual_seed(2)
+    r, rp = torch.randn(d["n"], h, generator=gen), torch.randn(d["n"], 3, generator=gen)
+    xc, pc = x.double().requires_grad_(True), pos.double().requires_grad_(True)
+    if egnn:
+        want, want_pos = O.egnn_full_layer(xc, pc, ei, ea.double(), params["fused_linear.weight"], params["linear_3.weight"],
+                                           params["linear_out.weight"], params["coord_linear.weight"])
+        ((want * r.double()).sum() + (want_pos * rp.double()).sum()).backward()
+    else:
+        want = O.layer_sum(xc, ei, ea.double(), params["fused_linear.weight"], params["linear_3.weight"],
+                           params["linear_out.weight"])
+        (want * r.double()).sum().backward()
+    c = dict(layer=layer, x=x, ea=ea, pos=pos, ei=ei, r=r, rp=rp)
+    got, got_pos, gx, gpos, grads, ei_dev = _run(c, torch.float32, egnn)
+    g = graph_for(ei_dev, d["n"])
+    assert g.islands.max_edges > 200 and islands.plan_for(g, f, h, fe, egnn) is not None
+    assert_close(got, want, 1e-5, what="y")
+    assert_close(gx, xc.grad, 1e-5, atol_scale=4.0, what="grad x")
+    if egnn:
+        assert_close(got_pos, want_pos, 1e-5, what="pos'")
+        assert_close(gpos, pc.grad, 1e-5, atol_scale=4.0, what="grad pos")
+    for k, gr in grads.items():
+        assert_close(gr, params[k].grad, 1e-5, atol_scale=4.0, what=f"grad {k}")
 
 
 def test_general_path_on_the_same_batch(islands_off):
