@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 11
+#define MPNN_ABI_VERSION 12
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -484,7 +484,9 @@ int32_t mpnn_knn_graph(const float* pos, int32_t num_clouds, int32_t points, int
  *
  * mpnn_islands_build finds the islands of a destination-sorted CSR (mpnn_csr_build output in row-id order):
  *   island_ptr [num_nodes + 1]: island i = nodes island_ptr[i] .. island_ptr[i+1]-1 (ascending, island_ptr[0] = 0)
- *   meta [4]: { number of islands, nodes of the largest island, edges of the largest island, 0 }
+ *   meta [4]: { number of islands, nodes of the largest island, edges of the largest island, gave up }
+ *   give_up > 0: stop as soon as one row alone spans that many nodes or more (its island is at least that large -
+ *   a k-NN cloud, a citation graph); meta then reads { 0, 0, 0, 1 } and island_ptr is unspecified.  0 = always finish.
  *   workspace: mpnn_islands_workspace_bytes(num_nodes) bytes.
  * A batch assembled by mpnn_collate can use its graph offsets (slot table row 0) as island_ptr directly.
  *
@@ -519,8 +521,9 @@ typedef struct mpnn_island_layer {
   float* partial; float* gx_part;
 } mpnn_island_layer;
 int64_t mpnn_islands_workspace_bytes(int64_t num_nodes);
-int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t* island_ptr,
-                           int32_t* meta, void* workspace, int64_t workspace_bytes, mpnn_stream_t stream);
+int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t give_up,
+                           int32_t* island_ptr, int32_t* meta, void* workspace, int64_t workspace_bytes,
+                           mpnn_stream_t stream);
 /* wavefronts (= islands) per block that fit the LDS for this shape; 0 = the shape is not supported */
 int32_t mpnn_island_layer_waves(int32_t F, int32_t H, int32_t Fe, int32_t egnn, int32_t backward);
 int64_t mpnn_island_layer_partial_floats(int32_t n_islands, int32_t tail_units, int32_t F, int32_t H, int32_t Fe,

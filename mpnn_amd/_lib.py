@@ -14,7 +14,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 MPNN_F32 = 0
 MPNN_BF16 = 1
 MPNN_U8 = 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -59,7 +59,7 @@ class IslandLayerDesc(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/mpnn_amd.h one to one.
 SIGNATURES = {
     "mpnn_islands_workspace_bytes": (c_int64, [c_int64]),
-    "mpnn_islands_build": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "mpnn_islands_build": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "mpnn_island_layer_waves": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "mpnn_island_layer_partial_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "mpnn_island_layer_fwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_void_p]),

@@ -48,8 +48,11 @@ __device__ __forceinline__ int block_scan_inclusive(int v, int* sm, Op op) {   /
 }
 
 // lo[r] / hi[r] = smallest / largest node id among row r and the sources of its edges.
+// A row that alone spans `give_up` nodes or more (give_up > 0) settles that the graph has an island at least that
+// large: meta[3] is set and the search stops there (every writer stores the same 1).
 __global__ void __launch_bounds__(256) k_island_bounds(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                       int n, int32_t* __restrict__ lo, int32_t* __restrict__ hi) {
+                                                       int n, int32_t* __restrict__ lo, int32_t* __restrict__ hi,
+                                                       int give_up, int32_t* __restrict__ meta) {
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
     int a = r, b = r;
     for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
@@ -59,6 +62,7 @@ __global__ void __launch_bounds__(256) k_island_bounds(const int32_t* __restrict
     }
     lo[r] = a;
     hi[r] = b;
+    if (give_up > 0 && b - a + 1 >= give_up) meta[3] = 1;
   }
 }
 
@@ -77,6 +81,10 @@ __global__ void __launch_bounds__(kScanBlock) k_islands_build(const int32_t* __r
   auto imin = [](int a, int b) { return a < b ? a : b; };
   auto imax = [](int a, int b) { return a > b ? a : b; };
   auto iadd = [](int a, int b) { return a + b; };
+  if (meta[3] != 0) {   // (the whole block reads the same word) an island too large for the caller: nothing to list
+    if (t == 0) { meta[0] = 0; meta[1] = 0; meta[2] = 0; }
+    return;
+  }
   if (t == 0) { max_nodes = 0; max_edges = 0; island_ptr[0] = 0; }
   __shared__ int totals[kScanBlock];
   int upto;
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(kScanBlock) k_islands_build(const int32_t* __r
   atomicMax(&max_nodes, mn);   // integer maxima: the order does not matter
   atomicMax(&max_edges, me);
   __syncthreads();
-  if (t == 0) { meta[0] = islands; meta[1] = max_nodes; meta[2] = max_edges; meta[3] = 0; }
+  if (t == 0) { meta[0] = islands; meta[1] = max_nodes; meta[2] = max_edges; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1158,18 +1166,20 @@ int64_t mpnn_islands_workspace_bytes(int64_t num_nodes) {
   return 2 * align_up((num_nodes + 1) * 4, 256);
 }
 
-int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t* island_ptr,
-                           int32_t* meta, void* workspace, int64_t workspace_bytes, mpnn_stream_t stream) {
+int32_t mpnn_islands_build(const int32_t* rowptr, const int32_t* col, int64_t num_nodes, int32_t give_up,
+                           int32_t* island_ptr, int32_t* meta, void* workspace, int64_t workspace_bytes,
+                           mpnn_stream_t stream) {
   if (num_nodes < 0 || num_nodes > INT32_MAX) return fail(MPNN_E_INVALID, "mpnn_islands_build: bad num_nodes");
   if (!rowptr || !island_ptr || !meta || !workspace) return fail(MPNN_E_INVALID, "mpnn_islands_build: null pointer argument");
   if (workspace_bytes < mpnn_islands_workspace_bytes(num_nodes))
     return fail(MPNN_E_CAPACITY, "mpnn_islands_build: workspace too small");
   int32_t* lo = static_cast<int32_t*>(workspace);
   int32_t* hi = lo + align_up((num_nodes + 1) * 4, 256) / 4;
+  MPNN_HIP_CHECK(hipMemsetAsync(meta, 0, 4 * sizeof(int32_t), stream));
   if (num_nodes > 0) {
     int64_t blocks = (num_nodes + 255) / 256;
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-    k_island_bounds<<<(int)blocks, 256, 0, stream>>>(rowptr, col, (int)num_nodes, lo, hi);
+    k_island_bounds<<<(int)blocks, 256, 0, stream>>>(rowptr, col, (int)num_nodes, lo, hi, give_up, meta);
     MPNN_LAUNCH_CHECK("k_island_bounds");
   }
   k_islands_build<<<1, kScanBlock, 0, stream>>>(rowptr, (int)num_nodes, lo, hi, island_ptr, meta);

@@ -31,6 +31,7 @@ ITEM_ORDER_MIN_EDGES = 1 << 22
 # the build, its result read back with the item counts); see Islands.  MPNN_AMD_ISLANDS=0 switches the search and
 # with it the one-launch layers off.
 ISLAND_SEARCH_MAX_NODES = 1 << 18
+ISLAND_GIVE_UP_NODES = 33        # one more than the largest island the one-launch layers take
 ISLANDS_ENABLED = os.environ.get("MPNN_AMD_ISLANDS", "1") != "0"
 
 
@@ -234,11 +235,13 @@ class MPGraph:
         lib = _lib.load()
         dev = self.by_dst.rowptr.device
         ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        meta = torch.zeros(6, dtype=torch.int32, device=dev)
+        meta = torch.empty(6, dtype=torch.int32, device=dev)    # the call clears the 4 entries it owns
         ws = torch.empty(lib.mpnn_islands_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        _lib.check(lib.mpnn_islands_build(_lib.ptr(self.by_dst.rowptr), _lib.ptr(self.by_dst.col), n, _lib.ptr(ptr),
-                                          _lib.ptr(meta), _lib.ptr(ws), ws.numel(), _lib.stream_handle(dev)),
-                   "mpnn_islands_build")
+        # a row that alone spans more nodes than the island kernels take ends the search at once (point clouds,
+        # citation graphs: the common case among the graphs that have no small islands)
+        _lib.check(lib.mpnn_islands_build(_lib.ptr(self.by_dst.rowptr), _lib.ptr(self.by_dst.col), n,
+                                          ISLAND_GIVE_UP_NODES, _lib.ptr(ptr), _lib.ptr(meta), _lib.ptr(ws), ws.numel(),
+                                          _lib.stream_handle(dev)), "mpnn_islands_build")
         return ptr, meta
 
     @classmethod

@@ -80,6 +80,20 @@ def test_islands_match_the_oracle(islands_on, case):
     want = O.islands(ei, n)
     g = MPGraph(ei.to(DEV), n)
     isl = g.islands
+    if case == "one-island":
+        # one row alone spans the whole graph: the graph build stops searching at the first such row ...
+        assert isl is None
+        # ... and the search itself, asked to finish, lists the single island
+        from mpnn_amd import _lib
+        lib = _lib.load()
+        ptr = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+        meta = torch.empty(4, dtype=torch.int32, device=DEV)
+        ws = torch.empty(lib.mpnn_islands_workspace_bytes(n), dtype=torch.uint8, device=DEV)
+        _lib.check(lib.mpnn_islands_build(_lib.ptr(g.by_dst.rowptr), _lib.ptr(g.by_dst.col), n, 0, _lib.ptr(ptr),
+                                          _lib.ptr(meta), _lib.ptr(ws), ws.numel(), _lib.stream_handle(ptr.device)),
+                   "mpnn_islands_build")
+        assert meta.tolist()[:2] == [1, n] and meta.tolist()[3] == 0 and ptr[:2].tolist() == want == [0, n]
+        return
     assert isl is not None and isl.count == len(want) - 1
     assert isl.ptr[:isl.count + 1].cpu().tolist() == want                      # bit-exact boundaries
     sizes = [b - a for a, b in zip(want[:-1], want[1:])]
@@ -251,7 +265,8 @@ def test_islands_too_large_or_too_many_use_the_general_path(islands_on, monkeypa
     from mpnn_amd.graph import MPGraph
     d = molecules(3, 50, max_nodes=40)
     g = MPGraph(d["edge_index"].to(DEV), d["n"])
-    assert g.islands.max_nodes == 40 and islands.plan_for(g, 11, 64, 4, False) is None
+    assert g.islands is None or g.islands.max_nodes == 40      # (None: a single row already spans 33 nodes or more)
+    assert islands.plan_for(g, 11, 64, 4, False) is None
     d = molecules(4, 50)
     g = MPGraph(d["edge_index"].to(DEV), d["n"])
     assert islands.plan_for(g, 11, 64, 4, False) is not None
