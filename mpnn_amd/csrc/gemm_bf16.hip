@@ -433,8 +433,10 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials_bf16(const float* __res
   for (int64_t base = (int64_t)blockIdx.x * 64; base < count; base += (int64_t)gridDim.x * 64) {
     const int64_t i = base + o;
     float s = 0.f;
-    if (i < count)
-      for (int b = g; b < nslabs; b += kBlock / 64) s += partial[(int64_t)b * count + i];
+    if (i < count) {
+#pragma unroll 8
+      for (int b = g; b < nslabs; b += kBlock / 64) s += partial[(int64_t)b * count + i];   // 8 loads in flight
+    }
     red[threadIdx.x] = s;
     __syncthreads();
     if (g == 0 && i < count) {
