@@ -67,7 +67,8 @@ def layer_bwd(gy: Tensor, x: Tensor, edge_index: Tensor, edge_attr: Tensor, ab: 
     graph = graph_for(edge_index, x.size(0))
     x = x if x.is_contiguous() and x.data_ptr() % 16 == 0 else x.clone(memory_format=torch.contiguous_format)
     one_launch = islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), False) is not None
-    ea_t = graph.sorted_edge_attr(edge_attr, x.dtype)[0 if one_launch else 1]   # the layout layer_fwd's path reads
+    # the layout layer_fwd's path reads
+    ea_t = graph.sorted_edge_attr(edge_attr, x.dtype, "dst")[0] if one_launch else graph.sorted_edge_attr(edge_attr, x.dtype)[1]
     bits = maskbits if maskbits.size(1) > 0 else None
     counts = (cnt, cnt_big if cnt_big.size(0) > 0 else None)
     grads = layer_fn.backward_impl(gy, x, ab, aggr, counts, bits, y, ea_t, w_nodes, w_edge, w_out, graph,

@@ -32,6 +32,9 @@ ITEM_ORDER_MIN_EDGES = 1 << 22
 # with it the one-launch layers off.
 ISLAND_SEARCH_MAX_NODES = 1 << 18
 ISLAND_GIVE_UP_NODES = 33        # one more than the largest island the one-launch layers take
+# An edge list with at most this many edges per node on average is taken for a batch of small graphs: its structure
+# is built in two steps (destination view + island search first, the rest only if a general kernel asks for it).
+SMALL_GRAPHS_MAX_DEGREE = 8
 ISLANDS_ENABLED = os.environ.get("MPNN_AMD_ISLANDS", "1") != "0"
 
 
@@ -76,7 +79,9 @@ class CSR:
 
 
 def _build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: int,
-               chunk: int, max_parts: int, item_order: bool = False) -> CSR:
+               chunk: int, max_parts: int, item_order: bool = False, with_items: bool = True) -> CSR:
+    """Sorted view + (with_items) its work items.  Returns (csr, pending record for _finish), or - without items -
+    (csr, (status, workspace)) for a later _build_items."""
     lib = _lib.load()
     dev = key.device
     E = key.numel()
@@ -97,6 +102,8 @@ def _build_csr(key: torch.Tensor, other: torch.Tensor, num_rows: int, num_cols: 
                                   stream), "mpnn_csr_build")
     if item_order:
         _rows_into_item_order(csr, status, chunk)
+    if not with_items:
+        return csr, (status, ws)
     return csr, _build_items(csr, chunk, max_parts, status, ws)
 
 
@@ -212,34 +219,88 @@ class MPGraph:
         if row_order not in ("natural", "items"):
             raise ValueError(f"row_order must be 'natural' or 'items', got {row_order!r}")
         by_items = row_order == "items" and self.num_edges > 0
-        self.by_dst, p1 = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts, by_items)
-        self.by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, by_items)
-        self.islands = None
-        found = self._search_islands() if (not by_items and self.num_dst == self.num_src) else None
-        meta = _finish([self.by_dst, self.by_src], [p1, p2], found[1] if found else None)
-        if found and meta[0] > 0:
-            self.islands = Islands(found[0], meta[0], meta[1], meta[2])
-        if by_items:
-            _rows_to_ids(self.by_dst)
-            _rows_to_ids(self.by_src)
         self._ea_key = None
         self._ea_sorted = None
         self._scratch = {}
         self._tpos = None
+        self._deferred = None
+        self.islands = None
+        search = not by_items and self.num_dst == self.num_src and ISLANDS_ENABLED and \
+            0 < self.num_dst <= ISLAND_SEARCH_MAX_NODES
+        if search and self.num_edges <= SMALL_GRAPHS_MAX_DEGREE * self.num_dst:
+            # Probably a batch of small graphs.  The one-launch layers need the destination view and the islands only:
+            # build those, read the result, and leave the work items and the whole source view for the first caller
+            # that takes the general path (none, for layers the island kernels cover).
+            self._by_dst, (status, ws) = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts, False, False)
+            ptr, meta = self._search_islands(self._by_dst)
+            bad, count, largest, most_edges = torch.cat([status[:1], meta[:3]]).tolist()   # the one host read
+            if bad != 0:
+                raise IndexError(f"edge_index holds node ids outside [0, {self.num_dst}) x [0, {self.num_src})")
+            if count > 0:
+                self.islands = Islands(ptr, count, largest, most_edges)
+            if count > 0 and largest < ISLAND_GIVE_UP_NODES:
+                self._by_src = None
+                self._deferred = (src, dst, chunk, max_parts, status, ws)
+                return
+            p1 = _build_items(self._by_dst, chunk, max_parts, status, ws)
+            self._by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, False)
+            _finish([self._by_dst, self._by_src], [p1, p2])
+            return
+        self._by_dst, p1 = _build_csr(dst, src, self.num_dst, self.num_src, chunk, max_parts, by_items)
+        self._by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, by_items)
+        found = self._search_islands(self._by_dst) if search else None
+        meta = _finish([self._by_dst, self._by_src], [p1, p2], found[1] if found else None)
+        if found and meta[0] > 0:
+            self.islands = Islands(found[0], meta[0], meta[1], meta[2])
+        if by_items:
+            _rows_to_ids(self._by_dst)
+            _rows_to_ids(self._by_src)
 
-    def _search_islands(self):
-        """Launches the island search over the destination view; (island_ptr, 6-entry result record) or None."""
+    def _complete(self) -> None:
+        """Builds what a two-phase build left out: the work items of the destination view and the source view."""
+        src, dst, chunk, max_parts, status, ws = self._deferred
+        self._deferred = None
+        p1 = _build_items(self._by_dst, chunk, max_parts, status, ws)
+        self._by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, False)
+        _finish([self._by_dst, self._by_src], [p1, p2])
+
+    @property
+    def by_dst(self) -> CSR:
+        """Destination-sorted view with its work items (what the general kernels walk)."""
+        if self._deferred is not None:
+            self._complete()
+        return self._by_dst
+
+    @by_dst.setter
+    def by_dst(self, csr: CSR) -> None:
+        self._by_dst = csr
+
+    @property
+    def by_src(self) -> CSR:
+        if self._deferred is not None:
+            self._complete()
+        return self._by_src
+
+    @by_src.setter
+    def by_src(self, csr: CSR) -> None:
+        self._by_src = csr
+
+    @property
+    def dst_rows(self) -> CSR:
+        """rowptr / col / eid of the destination view without asking for its work items."""
+        return self._by_dst
+
+    def _search_islands(self, csr: CSR):
+        """Launches the island search over the destination view; (island_ptr, 6-entry result record)."""
         n = self.num_dst
-        if not ISLANDS_ENABLED or n == 0 or n > ISLAND_SEARCH_MAX_NODES:
-            return None
         lib = _lib.load()
-        dev = self.by_dst.rowptr.device
+        dev = csr.rowptr.device
         ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         meta = torch.empty(6, dtype=torch.int32, device=dev)    # the call clears the 4 entries it owns
         ws = torch.empty(lib.mpnn_islands_workspace_bytes(n), dtype=torch.uint8, device=dev)
         # a row that alone spans more nodes than the island kernels take ends the search at once (point clouds,
         # citation graphs: the common case among the graphs that have no small islands)
-        _lib.check(lib.mpnn_islands_build(_lib.ptr(self.by_dst.rowptr), _lib.ptr(self.by_dst.col), n,
+        _lib.check(lib.mpnn_islands_build(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), n,
                                           ISLAND_GIVE_UP_NODES, _lib.ptr(ptr), _lib.ptr(meta), _lib.ptr(ws), ws.numel(),
                                           _lib.stream_handle(dev)), "mpnn_islands_build")
         return ptr, meta
@@ -250,6 +311,7 @@ class MPGraph:
         """Wraps index structures that were produced elsewhere (the batch assembler writes them directly)."""
         g = cls.__new__(cls)
         g.num_dst, g.num_src, g.num_edges = by_dst.num_rows, by_src.num_rows, by_dst.num_edges
+        g._deferred = None
         g.by_dst, g.by_src = by_dst, by_src
         g._ea_key = None
         g._ea_sorted = None
@@ -275,14 +337,26 @@ class MPGraph:
             self._tpos = inv[self.by_src.eid.long()].contiguous()
         return self._tpos
 
-    def sorted_edge_attr(self, edge_attr: torch.Tensor, dtype: torch.dtype):
-        """edge_attr laid out in CSR order and in transpose order (cached per tensor version)."""
+    def sorted_edge_attr(self, edge_attr: torch.Tensor, dtype: torch.dtype, views: str = "both"):
+        """edge_attr laid out in CSR order and in transpose order (cached per tensor version).  ``views="dst"``:
+        a 1-tuple with the CSR order only (all the one-launch layers read; it does not ask for the source view)."""
         key = (edge_attr.data_ptr(), edge_attr._version, tuple(edge_attr.shape), edge_attr.dtype, dtype)
         if self._ea_key == key:
             return self._ea_sorted
         if edge_attr.dim() != 2 or edge_attr.size(0) != self.num_edges:
             raise ValueError(f"edge_attr must have shape [{self.num_edges}, Fe], got {tuple(edge_attr.shape)}")
         lib = _lib.load()
+        if views == "dst":
+            hit = self._scratch.get("ea_dst")
+            if hit is not None and hit[0] == key:
+                return (hit[2],)
+            src = edge_attr.detach().to(dtype).contiguous()
+            out = torch.empty_like(src)
+            _lib.check(lib.mpnn_gather_rows(_lib.ptr(src), _lib.ptr(self._by_dst.eid), _lib.ptr(out), self.num_edges,
+                                            src.size(1) * src.element_size(), _lib.stream_handle(src.device)),
+                       "mpnn_gather_rows")
+            self._scratch["ea_dst"] = (key, edge_attr, out)   # (holds the tensor: its address cannot be reused)
+            return (out,)
         src = edge_attr.detach().to(dtype).contiguous()
         row_bytes = src.size(1) * src.element_size()
         outs = []

@@ -54,7 +54,7 @@ def _plan(isl, f: int, h: int, fe: int, egnn: bool) -> Plan | None:
 
 
 def _desc(plan: Plan, graph: MPGraph, x, ea_s, w_nodes, w_edge, w_out, y, pos=None, w_pos=None) -> _lib.IslandLayerDesc:
-    isl, csr = graph.islands, graph.by_dst
+    isl, csr = graph.islands, graph.dst_rows
     d = _lib.IslandLayerDesc()
     P = _lib.ptr
     d.rowptr, d.col, d.island_ptr = P(csr.rowptr), P(csr.col), P(isl.ptr)
@@ -78,7 +78,7 @@ def _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
     if edge_attr.requires_grad:
         raise NotImplementedError("gradient with respect to edge_attr is not implemented by the HIP engine")
     x = x if x.is_contiguous() else x.contiguous()
-    ea_s = graph.sorted_edge_attr(edge_attr, x.dtype)[0]
+    ea_s = graph.sorted_edge_attr(edge_attr, x.dtype, "dst")[0]
     return x, ea_s, w_nodes.contiguous(), w_edge.contiguous(), w_out.contiguous()
 
 
