@@ -1,0 +1,53 @@
+"""Randomised sweep of the one-launch layers for batches of small graphs: random numbers and sizes of graphs (up to 32
+nodes, some without edges, some dense with repeated edges and self loops), random input / edge widths, hidden 64 or
+128, MPNNLayerSum / MPNNLayerCat / EGNNLayer, float32 and bfloat16, with and without the input gradient, against the
+float64 oracle.  Usage: python tests/fuzz_islands.py [seed] [cases]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+from conftest import assert_close
+from test_gpu_islands import _layer_case, _run, RTOL, KINK
+from mpnn_amd import islands
+from mpnn_amd.graph import graph_for, clear_cache
+import test_gpu_islands as T
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+g = torch.Generator().manual_seed(seed)
+R = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+taken = 0
+for c in range(cases):
+    egnn = R(0, 2) == 0
+    mode = "sum" if egnn or R(0, 1) else "cat"
+    dtype = torch.bfloat16 if R(0, 2) == 0 else torch.float32
+    f = [R(1, 20), 4 * R(1, 16), 32 * R(1, 4)][R(0, 2)]
+    h = 64 if R(0, 3) else 128
+    fe = R(1, 8)
+    count, max_nodes, dense = R(1, 400), R(1, 32), R(0, 3) == 0
+    orig = T.molecules
+    T.molecules = lambda s, cnt, max_nodes=max_nodes, fe=4, f=11, dense=dense: orig(s, cnt, max_nodes, fe, f, dense)
+    try:
+        case = _layer_case(mode, dtype, f, h, fe, seed=1000 * seed + c, count=count, egnn=egnn)
+    finally:
+        T.molecules = orig
+    clear_cache()
+    got, got_pos, gx, gpos, grads, ei = _run(case, dtype, egnn)
+    graph = graph_for(ei, case["n"])
+    used = islands.plan_for(graph, f, h, fe, egnn) is not None
+    taken += used
+    rtol, kink = RTOL[dtype], KINK[dtype]
+    tag = f"case {c}: {'egnn' if egnn else mode} {str(dtype)[6:]} F={f} H={h} Fe={fe} graphs={count} max_nodes={max_nodes} dense={dense} islands={used}"
+    try:
+        assert_close(got.float(), case["want"], rtol, what="y")
+        assert_close(gx.float(), case["xc"].grad, rtol, atol_scale=4.0, what="grad x", kink_frac=kink)
+        if egnn:
+            assert_close(got_pos, case["want_pos"], rtol, what="pos'")
+            assert_close(gpos, case["pc"].grad, rtol, atol_scale=4.0, what="grad pos", kink_frac=kink)
+        for k, gr in grads.items():
+            assert_close(gr.float(), case["params"][k].grad, rtol, atol_scale=4.0, what=f"grad {k}", kink_frac=kink)
+    except AssertionError as e:
+        print("FAILED", tag, "::", e)
+        sys.exit(1)
+    print("ok", tag, flush=True)
+print(f"{cases} cases, {taken} through the island kernels")
