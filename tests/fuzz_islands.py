@@ -1,7 +1,7 @@
 """Randomised sweep of the one-launch layers for batches of small graphs: random numbers and sizes of graphs (up to 32
 nodes, some without edges, some dense with repeated edges and self loops), random input / edge widths, hidden 64 or
 128, MPNNLayerSum / MPNNLayerCat / EGNNLayer, float32 and bfloat16, with and without the input gradient, against the
-float64 oracle.  Usage: python tests/fuzz_islands.py [seed] [cases]"""
+float64 oracle.  Usage: python tests/fuzz_islands.py [seed] [cases] [only this case]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ import test_gpu_islands as T
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None
 g = torch.Generator().manual_seed(seed)
 R = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
 taken = 0
@@ -25,6 +26,8 @@ for c in range(cases):
     h = 64 if R(0, 3) else 128
     fe = R(1, 8)
     count, max_nodes, dense = R(1, 400), R(1, 32), R(0, 3) == 0
+    if only is not None and c != only:
+        continue
     orig = T.molecules
     T.molecules = lambda s, cnt, max_nodes=max_nodes, fe=4, f=11, dense=dense: orig(s, cnt, max_nodes, fe, f, dense)
     try:
@@ -37,15 +40,20 @@ for c in range(cases):
     used = islands.plan_for(graph, f, h, fe, egnn) is not None
     taken += used
     rtol, kink = RTOL[dtype], KINK[dtype]
+    # float32: a pre-activation within rounding of zero (about one in 1e7; a dense case has 2e6 of them) can take the
+    # other branch of the relu, which moves one row of the weight gradients and two rows of the input gradient by one
+    # message's share (tools/island_flip_debug.py shows the edge).  Let few entries off, and only by that much.
+    far = 2e-3 if dtype == torch.float32 else None
+    kink = 0.05 if dtype == torch.float32 else kink
     tag = f"case {c}: {'egnn' if egnn else mode} {str(dtype)[6:]} F={f} H={h} Fe={fe} graphs={count} max_nodes={max_nodes} dense={dense} islands={used}"
     try:
         assert_close(got.float(), case["want"], rtol, what="y")
-        assert_close(gx.float(), case["xc"].grad, rtol, atol_scale=4.0, what="grad x", kink_frac=kink)
+        assert_close(gx.float(), case["xc"].grad, rtol, atol_scale=4.0, what="grad x", kink_frac=kink, kink_max=far)
         if egnn:
             assert_close(got_pos, case["want_pos"], rtol, what="pos'")
-            assert_close(gpos, case["pc"].grad, rtol, atol_scale=4.0, what="grad pos", kink_frac=kink)
+            assert_close(gpos, case["pc"].grad, rtol, atol_scale=4.0, what="grad pos", kink_frac=kink, kink_max=far)
         for k, gr in grads.items():
-            assert_close(gr.float(), case["params"][k].grad, rtol, atol_scale=4.0, what=f"grad {k}", kink_frac=kink)
+            assert_close(gr.float(), case["params"][k].grad, rtol, atol_scale=4.0, what=f"grad {k}", kink_frac=kink, kink_max=far)
     except AssertionError as e:
         print("FAILED", tag, "::", e)
         sys.exit(1)
