@@ -632,6 +632,44 @@ def test_split_bf16_gemm_is_as_accurate_as_the_float32_matrix_cores(n, k1, k2, m
     assert err["split"] <= 2.0 * err["f32"] + 1e-7, err
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k1,k2,m,relu,masked,second", [
+    (128, 0, 256, False, False, False), (128, 128, 128, True, False, False), (128, 0, 128, False, True, True),
+    (256, 0, 128, False, True, False), (72, 40, 64, True, False, True), (128, 0, 100, False, False, False),
+    (20, 0, 36, False, False, True)])
+def test_gemm_nt_on_big_matrices(k1, k2, m, relu, masked, second, monkeypatch):
+    """Matrices of >= 2^17 rows take the pre-split weight images: float32 rounding level of the float64 product, bit
+    for bit the same as with the weights split inside the kernel, with a ragged last row step, a mask, relu and the
+    second output (byte-sized multiplier)."""
+    from mpnn_amd.dense import gemm_nt
+    n = 131_072 + 77
+    g = torch.Generator().manual_seed(k1 + m)
+    x1, x2 = torch.randn(n, k1, generator=g), (torch.randn(n, k2, generator=g) if k2 else None)
+    w = torch.randn(m, k1 + k2, generator=g) / (k1 + k2) ** 0.5
+    mask = torch.randn(n, k1, generator=g) if masked else None
+    emul = torch.randint(0, 200, (n, m), generator=g, dtype=torch.uint8) if second else None
+    ref = (x1.double() * (mask > 0) if masked else x1.double()) @ w[:, :k1].double().t()
+    if k2:
+        ref = ref + x2.double() @ w[:, k1:].double().t()
+    if relu:
+        ref = ref.relu()
+    cu = lambda t: t.cuda() if t is not None else None
+    wd = w.cuda()
+    out = {}
+    for form in ("default", "nosplit"):
+        if form != "default":
+            monkeypatch.setenv("MPNN_GEMM_NT", form)
+        wide = torch.zeros(n, m + 4, device="cuda") if second else None
+        y = gemm_nt(cu(x1), wd[:, :k1], cu(x2), wd[:, k1:] if k2 else None, mask1=cu(mask), relu=relu, emul=cu(emul),
+                    out2=wide[:, :m] if second else None)
+        assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6, form
+        if second:
+            assert_close(wide[:, :m], ref * emul.double(), 2e-6, what=f"Y2 ({form})")
+            assert float(wide[:, m:].abs().sum()) == 0.0
+        out[form] = y
+    assert torch.equal(out["default"], out["nosplit"])
+
+
 # --------------------------------------------------------------------------- bfloat16 layer node
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["sum", "cat"])
