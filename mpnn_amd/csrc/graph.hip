@@ -60,6 +60,15 @@ __global__ void k_unpack_sorted(const int32_t* __restrict__ sorted, const uint64
   }
 }
 
+// rocPRIM sorts up to 2^20 items by merge sort: some twenty launches of a few microseconds each for the edge list of
+// a mini-batch, most of what a per-batch graph build costs.  The keys here are narrow (node ids, degree classes), so
+// the one-sweep radix sort needs one or two digit passes; take it from MPNN_SORT_MERGE_LIMIT items on.
+#ifndef MPNN_SORT_MERGE_LIMIT
+#define MPNN_SORT_MERGE_LIMIT 65536
+#endif
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config,
+                                              MPNN_SORT_MERGE_LIMIT>;
+
 static unsigned key_bits(int64_t N) {
   unsigned b = 1;
   while (b < 31 && ((int64_t)1 << b) < N) ++b;
@@ -70,7 +79,7 @@ static hipError_t sort_temp_bytes(int64_t E, int64_t N, size_t& bytes) {
   bytes = 0;
   int32_t* kn = nullptr;
   uint64_t* vn = nullptr;
-  return rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, vn, vn, (size_t)E, 0u, key_bits(N), (hipStream_t)0);
+  return rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, kn, kn, vn, vn, (size_t)E, 0u, key_bits(N), (hipStream_t)0);
 }
 
 static int grid_for(int64_t n) {
@@ -180,7 +189,7 @@ static unsigned order_bits(int chunk) {
 static hipError_t order_temp_bytes(int64_t N, int chunk, size_t& bytes) {
   bytes = 0;
   int32_t* kn = nullptr;
-  return rocprim::radix_sort_pairs(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0), kn, (size_t)N, 0u,
+  return rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, kn, kn, rocprim::counting_iterator<int32_t>(0), kn, (size_t)N, 0u,
                                    order_bits(chunk), (hipStream_t)0);
 }
 
@@ -315,7 +324,7 @@ int32_t mpnn_csr_build(const int64_t* key, const int64_t* other, int64_t E, int6
   k_prepare_keys<<<grid_for(E), kBlock, 0, stream>>>(key, other, E, N, M, keys_in, pay_in, status);
   MPNN_LAUNCH_CHECK("k_prepare_keys");
   // Radix sort is stable, and the payload's low half is the original edge id, so equal keys stay in edge order.
-  MPNN_HIP_CHECK(rocprim::radix_sort_pairs(temp_ptr, temp, keys_in, keys_out, pay_in, pay_out, (size_t)E, 0u,
+  MPNN_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(temp_ptr, temp, keys_in, keys_out, pay_in, pay_out, (size_t)E, 0u,
                                            key_bits(N), stream));
   k_unpack_sorted<<<grid_for(E + 1), kBlock, 0, stream>>>(keys_out, pay_out, E, N, rowptr, col, eid);
   MPNN_LAUNCH_CHECK("k_unpack_sorted");
@@ -373,7 +382,7 @@ int32_t mpnn_items_build(const int32_t* rowptr, int64_t N, int32_t chunk, int32_
                                          rocprim::plus<int32_t>(), stream));
   if (N > 0) {
     size_t t3 = temp;
-    MPNN_HIP_CHECK(rocprim::radix_sort_pairs(temp_ptr, t3, key, key_sorted, rocprim::counting_iterator<int32_t>(0),
+    MPNN_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(temp_ptr, t3, key, key_sorted, rocprim::counting_iterator<int32_t>(0),
                                              order, (size_t)N, 0u, order_bits(chunk), stream));
   }
   k_item_fill_rows<<<grid_for(N), kBlock, 0, stream>>>(rowptr, N, chunk, max_parts, o_parts, o_split, order,
@@ -423,7 +432,7 @@ int32_t mpnn_csr_item_order(const int32_t* rowptr, const int32_t* col, const int
   k_row_order_keys<<<grid_for(N), kBlock, 0, stream>>>(rowptr, N, chunk, key);
   MPNN_LAUNCH_CHECK("k_row_order_keys");
   size_t t = (size_t)temp_need;
-  MPNN_HIP_CHECK(rocprim::radix_sort_pairs(temp_ptr, t, key, key_sorted, rocprim::counting_iterator<int32_t>(0), order,
+  MPNN_HIP_CHECK(rocprim::radix_sort_pairs<SortConfig>(temp_ptr, t, key, key_sorted, rocprim::counting_iterator<int32_t>(0), order,
                                            (size_t)N, 0u, order_bits(chunk), stream));
   k_degrees_in_order<<<grid_for(N + 1), kBlock, 0, stream>>>(rowptr, order, N, deg_o);
   MPNN_LAUNCH_CHECK("k_degrees_in_order");
