@@ -264,10 +264,17 @@ static void launch_nt_bf16(const NtBf16Args& a, hipStream_t stream) {
   constexpr int WROWS = 32 * MT * WC;
   dim3 grid((unsigned)blocks, (a.M + WROWS - 1) / WROWS);
   const size_t lds = (size_t)2 * (kBfBN + WROWS) * kBfRowB;
-  if (lds > 64 * 1024) {   // set once per kernel: the call is far slower than a launch
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<MT, WC>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)attr;
+  if (lds > 64 * 1024) {
+    // the attribute belongs to the kernel's image on ONE device: set once per kernel and device, with that device
+    // current (the call is far slower than a launch)
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_bf16<MT, WC>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+        __atomic_store_n(&done[dev], true, __ATOMIC_RELEASE);
+      // on failure the launch below fails for want of LDS and the caller's launch check reports it
+    }
   }
   k_gemm_nt_bf16<MT, WC><<<grid, kBlock * WC, lds, stream>>>(a);
 }

@@ -52,9 +52,7 @@ def main():
         mask = torch.randn(n, m, device=dev) if masked else None
         print(f"TN N={n} M={m} K={k}+{k2} mask={masked}: ", end="", flush=True)
         t = timeit(lambda: gemm_tn(g, x, mask=mask, x2=x2))
-        print(f"{t:7.1f} us | torch.mm ", end="", flush=True)
-        t2 = timeit(lambda: torch.mm(g.t(), x))
-        print(f"{t2:7.1f} us", flush=True)
+        print(f"{t:7.1f} us", flush=True)   # (torch.mm(g.t(), x) does not return under graph capture at these sizes)
 
 
 if __name__ == "__main__":
