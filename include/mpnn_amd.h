@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 12
+#define MPNN_ABI_VERSION 13
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -419,15 +419,20 @@ int32_t mpnn_gemm_tn_bf16(const void* G, int64_t ldg, const void* mask, int64_t 
  *
  * Replaces global_mean_pool(x, batch) at models/mpnn.py:54,150.  The CSR is built
  * with mpnn_csr_build(key = batch, other = arange(N)), so unsorted `batch` works too.
+ *
+ * num_averaged <= num_segments: the segments from num_averaged on are padding (the spare
+ * graph that holds the unused rows of a fixed-capacity batch, mpnn_collate): their output
+ * rows are zeros, their rows are not read and take a zero gradient.  Pass num_segments
+ * for the plain mean of every segment.
  * ------------------------------------------------------------------------- */
 int32_t mpnn_segment_mean_fwd(const void* x, int64_t ldx, const int32_t* rowptr,
                               const int32_t* col, void* out, int64_t ldo,
-                              int64_t num_segments, int32_t H, int32_t dtype,
-                              mpnn_stream_t stream);
+                              int64_t num_segments, int64_t num_averaged, int32_t H,
+                              int32_t dtype, mpnn_stream_t stream);
 int32_t mpnn_segment_mean_bwd(const void* gout, int64_t ldg, const int32_t* rowptr,
                               const int32_t* col, void* gx, int64_t ldgx,
-                              int64_t num_segments, int32_t H, int32_t dtype,
-                              mpnn_stream_t stream);
+                              int64_t num_segments, int64_t num_averaged, int32_t H,
+                              int32_t dtype, mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Loss and optimizer step (each a fixed sequence of launches, nothing read back to the host,

@@ -448,7 +448,8 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock) k_segment_mean_fwd(const T* __restrict__ x, int64_t ldx,
                                                              const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col, T* __restrict__ out,
-                                                             int64_t ldo, int64_t nseg, int H, int lpr_log2) {
+                                                             int64_t ldo, int64_t nseg, int64_t navg, int H,
+                                                             int lpr_log2) {
   extern __shared__ float lds[];
   const int lpr = 1 << lpr_log2;
   const int lig = threadIdx.x & (lpr - 1);
@@ -459,6 +460,15 @@ __global__ void __launch_bounds__(kBlock) k_segment_mean_fwd(const T* __restrict
   const bool act = c0 < H;
   const int cc = act ? c0 : 0;
   for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+    if (s >= navg) {   // a padding segment: its row is zeros, its (possibly very many) rows are not read
+      if (grp == 0 && act) {
+        float z[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+        RowIO<T, VEC>::store(out + s * ldo + c0, z);
+      }
+      continue;
+    }
     const int r0 = rowptr[s], r1 = rowptr[s + 1];
     float acc[VEC];
 #pragma unroll
@@ -492,14 +502,25 @@ template <typename T, int VEC>
 __global__ void __launch_bounds__(kBlock) k_segment_mean_bwd(const T* __restrict__ gout, int64_t ldg,
                                                              const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col, T* __restrict__ gx,
-                                                             int64_t ldgx, int64_t nseg, int H, int lpr_log2) {
+                                                             int64_t ldgx, int64_t nseg, int64_t navg, int H,
+                                                             int lpr_log2) {
   const int lpr = 1 << lpr_log2;
   const int lig = threadIdx.x & (lpr - 1);
   const int grp = threadIdx.x >> lpr_log2;
   const int ngrp = kBlock >> lpr_log2;
   const int c0 = blockIdx.y * (lpr * VEC) + lig * VEC;
   if (c0 >= H) return;
-  for (int64_t s = blockIdx.x; s < nseg; s += gridDim.x) {
+  if (navg < nseg) {
+    // the rows of the padding segments take no gradient; there may be many of them in one segment, so all blocks
+    // share the zero fill
+    float z[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) z[v] = 0.f;
+    const int z1 = rowptr[nseg];
+    for (int64_t p = rowptr[navg] + (int64_t)blockIdx.x * ngrp + grp; p < z1; p += (int64_t)gridDim.x * ngrp)
+      RowIO<T, VEC>::store(gx + (int64_t)col[p] * ldgx + c0, z);
+  }
+  for (int64_t s = blockIdx.x; s < navg; s += gridDim.x) {
     const int r0 = rowptr[s], r1 = rowptr[s + 1];
     if (r1 <= r0) continue;
     float g[VEC];
@@ -654,25 +675,28 @@ static int32_t run_bwd_masked(const void* G, int64_t ldG, const uint32_t* maskbi
 
 template <typename T, int VEC>
 static int32_t run_segmean(bool fwd, const void* in, int64_t ldin, const int32_t* rowptr, const int32_t* col,
-                           void* out, int64_t ldout, int64_t nseg, int32_t H, const Geometry& g, hipStream_t stream) {
+                           void* out, int64_t ldout, int64_t nseg, int64_t navg, int32_t H, const Geometry& g,
+                           hipStream_t stream) {
   int64_t blocks = nseg > kMaxBlocks ? kMaxBlocks : nseg;
   dim3 grid((unsigned)blocks, g.tiles);
   if (fwd) {
     const size_t lds = (size_t)(kBlock >> g.lpr_log2) * (1 << g.lpr_log2) * VEC * sizeof(float);
     k_segment_mean_fwd<T, VEC><<<grid, kBlock, lds, stream>>>(static_cast<const T*>(in), ldin, rowptr, col,
-                                                              static_cast<T*>(out), ldout, nseg, H, g.lpr_log2);
+                                                              static_cast<T*>(out), ldout, nseg, navg, H, g.lpr_log2);
   } else {
     k_segment_mean_bwd<T, VEC><<<grid, kBlock, 0, stream>>>(static_cast<const T*>(in), ldin, rowptr, col,
-                                                            static_cast<T*>(out), ldout, nseg, H, g.lpr_log2);
+                                                            static_cast<T*>(out), ldout, nseg, navg, H, g.lpr_log2);
   }
   MPNN_LAUNCH_CHECK("k_segment_mean");
   return MPNN_OK;
 }
 
 static int32_t segmean(bool fwd, const void* in, int64_t ldin, const int32_t* rowptr, const int32_t* col, void* out,
-                       int64_t ldout, int64_t nseg, int32_t H, int32_t dtype, hipStream_t stream) {
+                       int64_t ldout, int64_t nseg, int64_t navg, int32_t H, int32_t dtype, hipStream_t stream) {
   if (dtype != MPNN_F32 && dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "mpnn_segment_mean: dtype %d", dtype);
   if (H < 1 || nseg < 0) return fail(MPNN_E_INVALID, "mpnn_segment_mean: H=%d nseg=%lld", H, (long long)nseg);
+  if (navg < 0 || navg > nseg)
+    return fail(MPNN_E_INVALID, "mpnn_segment_mean: num_averaged=%lld outside [0, %lld]", (long long)navg, (long long)nseg);
   if (nseg == 0) return MPNN_OK;
   if (!in || !rowptr || !col || !out) return fail(MPNN_E_INVALID, "mpnn_segment_mean: null pointer argument");
   if (ldin < H || ldout < H) return fail(MPNN_E_INVALID, "mpnn_segment_mean: leading dimension below H");
@@ -680,11 +704,11 @@ static int32_t segmean(bool fwd, const void* in, int64_t ldin, const int32_t* ro
   const bool vec_ok = aligned16(in) && aligned16(out) && ldin % full == 0 && ldout % full == 0;
   const Geometry g = geometry(H, dtype, vec_ok);
   if (dtype == MPNN_F32) {
-    if (g.vec == 4) return run_segmean<float, 4>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
-    return run_segmean<float, 1>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
+    if (g.vec == 4) return run_segmean<float, 4>(fwd, in, ldin, rowptr, col, out, ldout, nseg, navg, H, g, stream);
+    return run_segmean<float, 1>(fwd, in, ldin, rowptr, col, out, ldout, nseg, navg, H, g, stream);
   }
-  if (g.vec == 8) return run_segmean<bf16_t, 8>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
-  return run_segmean<bf16_t, 1>(fwd, in, ldin, rowptr, col, out, ldout, nseg, H, g, stream);
+  if (g.vec == 8) return run_segmean<bf16_t, 8>(fwd, in, ldin, rowptr, col, out, ldout, nseg, navg, H, g, stream);
+  return run_segmean<bf16_t, 1>(fwd, in, ldin, rowptr, col, out, ldout, nseg, navg, H, g, stream);
 }
 
 }  // namespace mpnn
@@ -911,13 +935,15 @@ int32_t mpnn_aggregate_bwd_src_masked(const void* G, int64_t ldG, const uint32_t
 }
 
 int32_t mpnn_segment_mean_fwd(const void* x, int64_t ldx, const int32_t* rowptr, const int32_t* col, void* out,
-                              int64_t ldo, int64_t num_segments, int32_t H, int32_t dtype, mpnn_stream_t stream) {
-  return segmean(true, x, ldx, rowptr, col, out, ldo, num_segments, H, dtype, stream);
+                              int64_t ldo, int64_t num_segments, int64_t num_averaged, int32_t H, int32_t dtype,
+                              mpnn_stream_t stream) {
+  return segmean(true, x, ldx, rowptr, col, out, ldo, num_segments, num_averaged, H, dtype, stream);
 }
 
 int32_t mpnn_segment_mean_bwd(const void* gout, int64_t ldg, const int32_t* rowptr, const int32_t* col, void* gx,
-                              int64_t ldgx, int64_t num_segments, int32_t H, int32_t dtype, mpnn_stream_t stream) {
-  return segmean(false, gout, ldg, rowptr, col, gx, ldgx, num_segments, H, dtype, stream);
+                              int64_t ldgx, int64_t num_segments, int64_t num_averaged, int32_t H, int32_t dtype,
+                              mpnn_stream_t stream) {
+  return segmean(false, gout, ldg, rowptr, col, gx, ldgx, num_segments, num_averaged, H, dtype, stream);
 }
 
 }  // extern "C"

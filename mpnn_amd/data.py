@@ -108,6 +108,7 @@ class GraphStore:
         self.fused = self.max_degree <= CHUNK
         self.max_graph_nodes = int((self.node_ptr[1:] - self.node_ptr[:-1]).max()) if self.num_graphs else 0
         self._iota = torch.arange(0, dtype=torch.int32, device=dev)
+        self._staging = {}     # page-locked staging buffers of the slot tables, by shape (see _upload)
 
     @classmethod
     def from_batched(cls, d: dict) -> "GraphStore":
@@ -150,7 +151,8 @@ class GraphStore:
         size whatever the graphs hold (molecules differ in size).  Rows past the real nodes are zero features that
         belong to one extra graph (``batch`` value = number of graphs) and have no edges; entries past the real
         edges are outside the sorted structure the layers use.  A model therefore returns one extra pooled row
-        (the last), and every real row equals the unpadded result.  A padded batch passed as ``out`` is refilled
+        (the last; global_mean_pool sets it to zero and passes no gradient to the padding rows), and every real
+        row equals the unpadded result.  A padded batch passed as ``out`` is refilled
         by any ``ids`` of the same count that fit - the real sizes travel in the slot table on the device, so the
         refill and the training step can be replayed from one HIP graph."""
         table = self.slot_table(ids)
@@ -165,7 +167,7 @@ class GraphStore:
                     raise ValueError(f"batch of {n} nodes / {e} edges exceeds the capacity {out.capacity}")
             elif (out.num_nodes, out.edge_index.size(1)) != (n, e):
                 raise ValueError("collate(out=...) needs a batch of identical size (or a padded batch)")
-            out._parts["slots"].copy_(torch.from_numpy(table), non_blocking=True)
+            self._upload(table, out._parts["slots"])
             self._launch(out._parts, b, n, e, out.capacity)
             # The launch rewrote edge_index, edge_attr and batch through raw pointers, which leaves their version
             # counters (the caches' staleness test) unchanged: put the structures that were rewritten with them
@@ -186,7 +188,7 @@ class GraphStore:
         o = 2 * (n_out + 1)
         ea3 = torch.empty((3, e_out) + tuple(self.edge_attr.shape[1:]), dtype=self.edge_attr.dtype, device=dev)
         parts = dict(
-            slots=torch.from_numpy(table).to(dev, non_blocking=True),
+            slots=self._upload(table, torch.empty(table.shape, dtype=torch.int32, device=dev)),
             x=torch.empty((n_out,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=dev),
             pos=torch.empty((n_out,) + tuple(self.pos.shape[1:]), dtype=self.pos.dtype, device=dev) if self.pos is not None else None,
             y=torch.empty((b,) + tuple(self.y.shape[1:]), dtype=self.y.dtype, device=dev) if self.y is not None else None,
@@ -219,6 +221,30 @@ class GraphStore:
         self._register(res, n)
         return res
 
+    def _upload(self, table: np.ndarray, dst: torch.Tensor) -> torch.Tensor:
+        """The slot table to the device without stopping the host.  A copy from ordinary host memory waits for the
+        stream to reach it, which would serialise the host's work on the next batch with the GPU's work on this one;
+        from page-locked memory it is queued like a kernel.  Four staging buffers per table shape take turns, each
+        guarded by an event recorded after its copy."""
+        if dst.device.type != "cuda":
+            dst.copy_(torch.from_numpy(table))
+            return dst
+        ring = self._staging.get(table.shape)
+        if ring is None:
+            ring = self._staging[table.shape] = {"bufs": [], "events": [], "next": 0}
+        if len(ring["bufs"]) < 4:
+            ring["bufs"].append(torch.empty(table.shape, dtype=torch.int32, pin_memory=True))
+            ring["events"].append(torch.cuda.Event())
+            i = len(ring["bufs"]) - 1
+        else:
+            i = ring["next"]
+            ring["events"][i].synchronize()      # its copy of four uploads ago: long done
+        ring["next"] = (i + 1) % 4
+        ring["bufs"][i].numpy()[...] = table
+        dst.copy_(ring["bufs"][i], non_blocking=True)
+        ring["events"][i].record(torch.cuda.current_stream(dst.device))
+        return dst
+
     def _register(self, batch: Batch, n: int) -> None:
         """Makes the layers and the pooling find the structures mpnn_collate just wrote for ``batch`` (after a
         first assembly and after every refill through ``out=``)."""
@@ -232,7 +258,7 @@ class GraphStore:
             # first use - never reuse one built from the buffer's earlier contents
             forget_graph(parts["edge_index"])
         if batch.capacity is not None:   # graphs 0 .. b-1 and the padding graph b
-            register_pool(parts["batch"], b + 1, parts["pool_rowptr"], self._iota[:n_out])
+            register_pool(parts["batch"], b + 1, parts["pool_rowptr"], self._iota[:n_out], averaged=b)
         else:
             register_pool(parts["batch"], b, parts["slots"][0], self._iota[:n])
 

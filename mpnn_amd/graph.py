@@ -61,11 +61,12 @@ class CSR:
     """One sorted view of the edge list (see mpnn_csr_build / mpnn_items_build)."""
 
     __slots__ = ("num_rows", "num_cols", "num_edges", "rowptr", "col", "eid", "items", "split",
-                 "n_items", "n_parts", "n_split", "order", "n_big")
+                 "n_items", "n_parts", "n_split", "order", "n_big", "averaged")
 
     def __init__(self):
         self.order = None
         self.n_big = 0      # unsplit rows with more than 255 edges: the first n_big unsplit work items
+        self.averaged = None   # pooling segments: rows that are real graphs (None = all), see ops.register_pool
 
     def degree(self) -> torch.Tensor:
         """Edges per row, indexed by row id."""

@@ -328,13 +328,18 @@ def egnn_aggregate(A, B, edge_attr, We, pos, w_pos, graph: MPGraph):
 # ----------------------------------------------------------------------------------------
 # segment mean (global_mean_pool)
 # ----------------------------------------------------------------------------------------
+def _averaged(csr: CSR) -> int:
+    """Segments that are real graphs; the ones after them are the padding of a fixed-capacity batch (register_pool)."""
+    return csr.num_rows if csr.averaged is None else csr.averaged
+
+
 def segment_mean_forward(x: torch.Tensor, csr: CSR) -> torch.Tensor:
     lib = _lib.load()
     x = x if x.stride(-1) == 1 else x.contiguous()
     H = x.size(1)
     out = torch.empty((csr.num_rows, H), dtype=x.dtype, device=x.device)
     _lib.check(lib.mpnn_segment_mean_fwd(_lib.ptr(x), x.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
-                                         _lib.ptr(out), out.stride(0), csr.num_rows, H,
+                                         _lib.ptr(out), out.stride(0), csr.num_rows, _averaged(csr), H,
                                          _lib.dtype_code(x.dtype), _lib.stream_handle(x.device)),
                "mpnn_segment_mean_fwd")
     return out
@@ -346,7 +351,7 @@ def segment_mean_backward(g: torch.Tensor, csr: CSR, n: int) -> torch.Tensor:
     H = g.size(1)
     gx = torch.empty((n, H), dtype=g.dtype, device=g.device)
     _lib.check(lib.mpnn_segment_mean_bwd(_lib.ptr(g), g.stride(0), _lib.ptr(csr.rowptr), _lib.ptr(csr.col),
-                                         _lib.ptr(gx), gx.stride(0), csr.num_rows, H,
+                                         _lib.ptr(gx), gx.stride(0), csr.num_rows, _averaged(csr), H,
                                          _lib.dtype_code(g.dtype), _lib.stream_handle(g.device)),
                "mpnn_segment_mean_bwd")
     return gx
@@ -367,13 +372,17 @@ class _SegmentMean(torch.autograd.Function):
 _POOL_CACHE = {}
 
 
-def register_pool(batch: torch.Tensor, num_graphs: int, rowptr: torch.Tensor, col: torch.Tensor) -> None:
+def register_pool(batch: torch.Tensor, num_graphs: int, rowptr: torch.Tensor, col: torch.Tensor,
+                  averaged: int | None = None) -> None:
     """Seeds the segment structure of ``batch`` (sorted, graph b owns nodes rowptr[b]:rowptr[b+1]; ``col`` is
     the node list in segment order) so that global_mean_pool need not derive it - the batch assembler
-    already knows it."""
+    already knows it.  ``averaged`` < num_graphs: the graphs from there on are padding (the spare graph of a
+    fixed-capacity batch, which may hold thousands of unused rows): their pooled rows are zeros and their nodes take
+    a zero gradient, without a pass over them."""
     csr = CSR()
     csr.num_rows, csr.num_cols, csr.num_edges = int(num_graphs), batch.numel(), batch.numel()
     csr.rowptr, csr.col = rowptr, col
+    csr.averaged = int(num_graphs) if averaged is None else int(averaged)
     _POOL_CACHE.clear()
     _POOL_CACHE[(batch.data_ptr(), batch._version, batch.numel(), str(batch.device), None)] = (batch, csr)
 

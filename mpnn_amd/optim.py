@@ -2,9 +2,11 @@
 
 Same update rule and defaults as ``torch.optim.Adam(params, lr)`` the reference constructs
 (experiments/flickr_exp.py:26, qm9_exp.py:33, modelnet_exp.py:49): betas (0.9, 0.999), eps 1e-8, no weight
-decay, no amsgrad.  The parameters are re-pointed at slices of one float32 buffer and so are their ``.grad``
-tensors, so ``zero_grad()`` is one memset, ``step()`` one call, and neither reads anything back to the host:
-the step counter lives on the device, which lets a whole training step be captured into a HIP graph.
+decay, no amsgrad.  The parameters are re-pointed at slices of one float32 buffer; ``zero_grad()`` drops the
+gradients (as torch's optimizers do by default), ``step()`` moves whatever autograd left in ``.grad`` into the
+matching slices of one gradient buffer with a single multi-tensor copy and updates everything in one library call.
+Nothing is read back to the host: the step counter lives on the device, which lets a whole training step be
+captured into a HIP graph.
 """
 from __future__ import annotations
 
@@ -39,23 +41,40 @@ class FlatAdam:
                 p.grad = self.flat_grad[off:off + k].view(p.shape)
                 off += k
 
-    def zero_grad(self, set_to_none: bool = False) -> None:
-        """Keeps the gradient tensors (they are views of the flat buffer) and clears them in one pass."""
-        self.flat_grad.zero_()
-
-    def gather_stray_gradients(self) -> None:
-        """Makes ``flat_grad`` hold every gradient: one that autograd replaced instead of accumulating into is copied
-        back and the parameter re-pointed at its slice."""
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        """Default: drops the gradients, so that backward hands its freshly written tensors over instead of adding
+        them to zeros with one launch per parameter.  ``set_to_none=False`` keeps ``.grad`` as views of the flat
+        buffer and clears it in one pass."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+            return
         off = 0
         for p in self.params:
             k = p.numel()
-            if p.grad is None:
-                self.flat_grad[off:off + k].zero_()
-                p.grad = self.flat_grad[off:off + k].view(p.shape)
-            elif p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
-                self.flat_grad[off:off + k].copy_(p.grad.reshape(-1))
-                p.grad = self.flat_grad[off:off + k].view(p.shape)
+            p.grad = self.flat_grad[off:off + k].view(p.shape)
             off += k
+        self.flat_grad.zero_()
+
+    def gather_stray_gradients(self) -> None:
+        """Makes ``flat_grad`` hold every gradient and every ``.grad`` a view of it: gradients that live elsewhere
+        (whatever backward produced after zero_grad) are copied into their slices by one multi-tensor copy; a
+        parameter without a gradient gets zeros."""
+        off = 0
+        slots, strays = [], []
+        for p in self.params:
+            k = p.numel()
+            slot = self.flat_grad[off:off + k].view(p.shape)
+            if p.grad is None:
+                slot.zero_()
+                p.grad = slot
+            elif p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+                slots.append(slot)
+                strays.append(p.grad.detach())
+                p.grad = slot
+            off += k
+        if strays:
+            torch._foreach_copy_(slots, strays)
 
     def step(self) -> None:
         self.gather_stray_gradients()

@@ -99,9 +99,10 @@ class Trainer_Flickr:
 class CapturedStep:
     """One training step as a HIP graph.
 
-    ``step_fn()`` must run the whole step on tensors that stay where they are (zero_grad that keeps the gradient
-    tensors, forward, loss, backward, optimizer step without host reads - e.g. FlatAdam) and return the loss
-    tensor.  ``replay()`` relaunches it and returns that same (device) loss tensor."""
+    ``step_fn()`` must run the whole step on inputs and parameters that stay where they are (zero_grad, forward,
+    loss, backward, optimizer step without host reads - e.g. FlatAdam; tensors created inside the step, gradients
+    included, come from the graph's own memory pool and keep their addresses from replay to replay) and return the
+    loss tensor.  ``replay()`` relaunches it and returns that same (device) loss tensor."""
 
     def __init__(self, step_fn, warmup: int = 3):
         side = torch.cuda.Stream()

@@ -250,6 +250,33 @@ def test_model_on_a_padded_batch_equals_the_exact_batch():
 
 
 @pytest.mark.gpu
+def test_pool_of_a_padded_batch_leaves_the_padding_graph_out():
+    """global_mean_pool on a padded batch: the real graphs' rows are those of the exact batch bit for bit, the spare
+    graph's row is zero whatever its (thousands of) padding rows hold, and those rows take a zero gradient."""
+    from mpnn_amd import global_mean_pool
+    from mpnn_amd.graph import clear_cache
+    store, _ = _store_and_cpu("qm9", 64)
+    ids = list(range(5, 37))
+    exact = store.collate(ids)
+    n = exact.num_nodes
+    gen = torch.Generator().manual_seed(4)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn(store.capacity_for(len(ids))[0], 64, generator=gen).cuda().to(dtype)
+        r = torch.randn(len(ids) + 1, 64, generator=gen).cuda().to(dtype)
+        xe = x[:n].clone().requires_grad_(True)
+        want = global_mean_pool(xe, exact.batch)
+        want.backward(r[:-1])
+        pad = store.collate(ids, capacity=store.capacity_for(len(ids)))
+        xp = x.clone().requires_grad_(True)
+        got = global_mean_pool(xp, pad.batch)
+        got.backward(r)
+        assert got.shape == (len(ids) + 1, 64)
+        assert torch.equal(got[:-1], want) and float(got[-1].abs().sum()) == 0.0
+        assert torch.equal(xp.grad[:n], xe.grad) and float(xp.grad[n:].abs().sum()) == 0.0
+    clear_cache()
+
+
+@pytest.mark.gpu
 def test_captured_batch_step_trains_like_the_eager_loop():
     """Molecule batches of varying size through one recorded step: same losses and weights as the eager loop
     (to float32 rounding: the padded weight-gradient sums group their rows differently)."""
