@@ -473,7 +473,19 @@ __global__ void __launch_bounds__(kBlock) k_segment_mean_fwd(const T* __restrict
     float acc[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-    for (int p = r0 + grp; p < r1; p += ngrp) {
+    // four rows in flight per lane group (a point cloud's segment has a thousand rows and one block); the rows are
+    // added in the same order as one by one
+    int p = r0 + grp;
+    for (; p + 3 * ngrp < r1; p += 4 * ngrp) {
+      float xv[4][VEC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) RowIO<T, VEC>::load(x + (int64_t)col[p + u * ngrp] * ldx + cc, xv[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += xv[u][v];
+    }
+    for (; p < r1; p += ngrp) {
       float xv[VEC];
       RowIO<T, VEC>::load(x + (int64_t)col[p] * ldx + cc, xv);
 #pragma unroll
@@ -528,7 +540,15 @@ __global__ void __launch_bounds__(kBlock) k_segment_mean_bwd(const T* __restrict
     const float cnt = (float)(r1 - r0);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) g[v] = g[v] / cnt;
-    for (int p = r0 + grp; p < r1; p += ngrp) RowIO<T, VEC>::store(gx + (int64_t)col[p] * ldgx + c0, g);
+    int p = r0 + grp;
+    for (; p + 3 * ngrp < r1; p += 4 * ngrp) {   // the four row ids requested together
+      int rows[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rows[u] = col[p + u * ngrp];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) RowIO<T, VEC>::store(gx + (int64_t)rows[u] * ldgx + c0, g);
+    }
+    for (; p < r1; p += ngrp) RowIO<T, VEC>::store(gx + (int64_t)col[p] * ldgx + c0, g);
   }
 }
 

@@ -1137,12 +1137,13 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict
 }
 
 // Number of row-slab walkers (gridDim.x) of the TN kernel: enough blocks to fill the chip (two 64 KiB-LDS
-// blocks per CU over all output tiles), but at least 8 slabs of 32 rows per walker so that the partial tiles
-// written and re-read stay small next to the operands.
+// blocks per CU over all output tiles), but at least 4 slabs of 32 rows per walker so that the partial tiles
+// written and re-read stay small next to the operands (8 was 10-20 % slower on matrices of 30-90 thousand rows,
+// whose walkers then cover half the chip; 2 is no faster than 4).
 static int tn_slabs(int64_t N, int M, int K) {
   const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
   int64_t slabs = 512 / tiles;
-  const int64_t need = ((N + 31) / 32 + 7) / 8;   // in 32-row units whatever the kernel's slab height
+  const int64_t need = ((N + 31) / 32 + 3) / 4;   // in 32-row units whatever the kernel's slab height
   if (slabs > need) slabs = need;
   if (slabs < 1) slabs = 1;
   return (int)slabs;
