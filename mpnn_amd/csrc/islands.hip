@@ -827,6 +827,16 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
   }
   __syncthreads();
   ISLAND_PROF(4);
+  {
+    // a block whose tiles all dropped out (padding rows of a fixed-capacity batch): its share of every weight gradient
+    // is zero - write that and leave
+    int live = 0;
+    for (int w2 = 0; w2 < wpb; ++w2) live |= nrows[w2];
+    if (live == 0) {
+      for (int64_t i = threadIdx.x; i < a.partial_stride; i += blockDim.x) part[i] = 0.f;
+      return;
+    }
+  }
   // gW_out = gz^T [x | aggr] over the rows of the whole block
   {
     const int ktiles = (F + H + 31) / 32;
