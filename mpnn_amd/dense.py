@@ -242,3 +242,58 @@ def update(x: torch.Tensor, aggr: torch.Tensor, w_out: torch.Tensor) -> torch.Te
     if x.dtype == torch.bfloat16:
         x, aggr = x.contiguous(), aggr.contiguous()
     return _Update.apply(x, aggr, w_out)
+
+
+_ONES = {}
+
+
+def _ones(n: int, device) -> torch.Tensor:
+    """[n, 1] ones (the right-hand side that turns a weight-gradient product into column sums), kept per device."""
+    t = _ONES.get(device)
+    if t is None or t.size(0) < n:
+        t = _ONES[device] = torch.ones((max(n, 1024), 1), dtype=torch.float32, device=device)
+    return t[:n]
+
+
+class _Head(torch.autograd.Function):
+    """y = x W^T + b on the library's GEMMs.  The backward of a node-level head (models/mpnn.py:99-101 on 89,250 rows)
+    is two reductions over the rows - the weight gradient g^T x and the bias gradient, the column sums of g; both
+    come out of one weight-gradient product over [x | 1]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        y = gemm_nt(x, w)
+        return y.add_(b) if b is not None else y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = _rows(g)
+        k = x.size(1)
+        gx = gemm_nt(g, w.t().contiguous()) if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[2]:
+            both = gemm_tn(g, x, x2=_ones(x.size(0), x.device))
+            gw, gb = both[:, :k].contiguous(), both[:, k].contiguous()
+        elif ctx.needs_input_grad[1]:
+            gw = gemm_tn(g, x)
+        return gx, gw, gb
+
+
+HEAD_MIN_ROWS = 4096
+
+
+@torch.compiler.disable
+def _head(x, weight, bias):
+    return _Head.apply(x if x.stride(-1) == 1 else x.contiguous(), weight, bias)
+
+
+def head(x: torch.Tensor, linear: torch.nn.Linear) -> torch.Tensor:
+    """``linear(x)`` for the output layer of a model.  Tall float32 inputs (a node-level head: one row per node) go
+    through the library's GEMMs, whose weight-gradient product reduces over the rows in one pass; the few pooled rows
+    of a graph-level head, bfloat16 models and traced (torch.compile) calls stay with the module itself."""
+    if (x.is_cuda and x.dtype == torch.float32 and linear.weight.dtype == torch.float32 and x.dim() == 2
+            and x.size(0) >= HEAD_MIN_ROWS and not torch.compiler.is_compiling()):
+        return _head(x, linear.weight, linear.bias)
+    return linear(x)

@@ -11,6 +11,7 @@ from torch.nn import Linear
 
 from .layers import EGNNLayer, MPNNLayerCat, MPNNLayerSum
 from . import compiled_ops
+from .dense import head
 from .ops import global_mean_pool
 
 
@@ -42,7 +43,7 @@ class MPNN(torch.nn.Module):
     def forward(self, x, edge_index, edge_attr):
         for layer in self.layers:
             x = _relu_after(layer, layer(x, edge_index, edge_attr))
-        return self.output_layer(x)
+        return head(x, self.output_layer)
 
 
 class _PooledMPNN(torch.nn.Module):

@@ -670,6 +670,31 @@ def test_gemm_nt_on_big_matrices(k1, k2, m, relu, masked, second, monkeypatch):
     assert torch.equal(out["default"], out["nosplit"])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k,m", [(5000, 64, 7), (89_250, 64, 7), (4100, 128, 19)])
+def test_node_level_head_matches_torch_linear(n, k, m):
+    """dense.head on a tall input: output, input gradient, weight gradient and bias gradient (the column sums that come
+    out of the same product as the weight gradient) against float64; short inputs stay with the module."""
+    from mpnn_amd import dense
+    torch.manual_seed(n)
+    lin = torch.nn.Linear(k, m).cuda()
+    gen = torch.Generator().manual_seed(m)
+    x, r = torch.randn(n, k, generator=gen), torch.randn(n, m, generator=gen)
+    xd = x.double().requires_grad_(True)
+    wd, bd = lin.weight.detach().double().cpu().requires_grad_(True), lin.bias.detach().double().cpu().requires_grad_(True)
+    (torch.nn.functional.linear(xd, wd, bd) * r.double()).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = dense.head(xg, lin)
+    assert y.grad_fn is not None and "Head" in type(y.grad_fn).__name__
+    (y * r.cuda()).sum().backward()
+    assert_close(y, torch.nn.functional.linear(xd, wd, bd), RTOL32, what="head output")
+    assert_close(xg.grad, xd.grad, RTOL32, what="grad x")
+    assert_close(lin.weight.grad, wd.grad, RTOL32, what="grad weight")
+    assert_close(lin.bias.grad, bd.grad, RTOL32, what="grad bias")
+    short = dense.head(x[:100].cuda(), lin)
+    assert "Head" not in type(short.grad_fn).__name__
+
+
 # --------------------------------------------------------------------------- bfloat16 layer node
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["sum", "cat"])
