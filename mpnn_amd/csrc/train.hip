@@ -61,16 +61,23 @@ __global__ void __launch_bounds__(kBlock) k_masked_ce(const float* __restrict__ 
   }
 }
 
-// result[0] = sum(loss) / sum(count), result[1] = 1 / sum(count); partials added in block order.
+// result[0] = sum(loss) / sum(count), result[1] = 1 / sum(count).  One wavefront: lane l adds the partials of blocks
+// l, l + 64, .. in ascending order, then the 64 sums meet in a fixed tree - the same order on every run.
 __global__ void k_ce_finish(const float* __restrict__ partial, int blocks, float* __restrict__ result) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   float loss = 0.f, cnt = 0.f;
-  for (int b = 0; b < blocks; ++b) {
+  for (int b = threadIdx.x; b < blocks; b += 64) {
     loss += partial[2 * b];
     cnt += partial[2 * b + 1];
   }
-  result[0] = loss / cnt;
-  result[1] = 1.f / cnt;
+  for (int off = 32; off > 0; off >>= 1) {
+    loss += __shfl_down(loss, off, 64);
+    cnt += __shfl_down(cnt, off, 64);
+  }
+  if (threadIdx.x == 0) {
+    result[0] = loss / cnt;
+    result[1] = 1.f / cnt;
+  }
 }
 
 // state[0] = step count (as float, exact below 2^24), state[1] = lr / (1 - b1^t), state[2] = sqrt(1 - b2^t)
