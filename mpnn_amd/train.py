@@ -132,10 +132,14 @@ class CapturedBatchStep:
     number of graphs (the short last batch of an epoch) runs eagerly through the same functions.
     The optimizer must not read the device (``mpnn_amd.optim.FlatAdam``)."""
 
-    def __init__(self, model, optimizer, loss_fn, store, batch_size: int, features: str = "x", loss_of=None):
+    def __init__(self, model, optimizer, loss_fn, store, batch_size: int, features: str = "x", loss_of=None,
+                 call=None):
         self.model, self.optimizer, self.loss_fn, self.store = model, optimizer, loss_fn, store
         self.batch_size, self.features = int(batch_size), features
         self.loss_of = loss_of or (lambda out, b: loss_fn(out[0], b.y[0]))
+        # how the model takes a batch: the pooled models' forward(x, edge_index, batch, edge_attr) (models/mpnn.py:38)
+        # unless told otherwise, e.g. call=lambda m, b: m(b.x, b.pos, b.edge_index, b.batch, b.edge_attr) for EGNN
+        self.call = call or (lambda m, b: m(getattr(b, self.features), b.edge_index, b.batch, b.edge_attr))
         if not (hasattr(optimizer, "state_snapshot") and hasattr(optimizer, "state_restore")):
             raise TypeError("CapturedBatchStep runs warm-up steps before recording and must put the optimizer back: "
                             "it needs state_snapshot() / state_restore() (mpnn_amd.optim.FlatAdam has them)")
@@ -146,7 +150,7 @@ class CapturedBatchStep:
 
     def _step(self, b):
         self.optimizer.zero_grad()
-        out = self.model(getattr(b, self.features), b.edge_index, b.batch, b.edge_attr)
+        out = self.call(self.model, b)
         loss = self.loss_of(out, b)
         loss.backward()
         self.optimizer.step()

@@ -308,6 +308,38 @@ def test_captured_batch_step_trains_like_the_eager_loop():
     clear_cache()
 
 
+@pytest.mark.gpu
+def test_captured_batch_step_with_the_egnn_model():
+    """The coordinate-threading model through the recorded step (call= says how it takes a batch): same losses and
+    weights as the eager loop on the exact batches."""
+    from mpnn_amd import EGNN
+    from mpnn_amd.optim import FlatAdam
+    from mpnn_amd.train import CapturedBatchStep
+    from mpnn_amd.graph import clear_cache
+    store, _ = _store_and_cpu("qm9", 40)
+    assert store.pos is not None
+    call = lambda m, b: m(b.x, b.pos, b.edge_index, b.batch, b.edge_attr)
+    models, opts = [], []
+    for _ in range(2):
+        torch.manual_seed(3)
+        m = EGNN(11, 4, 64, 19, num_layers=2).cuda()
+        models.append(m)
+        opts.append(FlatAdam(m.parameters(), lr=1e-2))
+    loss_of = lambda out, b: F.mse_loss(out[:b.num_graphs], b.y)
+    fast = CapturedBatchStep(models[1], opts[1], F.mse_loss, store, batch_size=8, loss_of=loss_of, call=call)
+    for ids in (list(range(0, 8)), list(range(16, 24)), [39, 3, 17, 5, 33, 8, 1, 30]):
+        b = store.collate(ids)
+        opts[0].zero_grad()
+        le = loss_of(call(models[0], b), b)
+        le.backward()
+        opts[0].step()
+        lc = fast.train(ids)
+        assert_close(lc.reshape(1), le.detach().reshape(1).double().cpu(), 1e-4, what=f"loss of batch {ids[:2]}..")
+    for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+        assert_close(pb, pa.detach().double().cpu(), 1e-3, what="weights")
+    clear_cache()
+
+
 def _hub_store(dev):
     """Graphs of identical size whose node 0 receives an edge from every other node of the graph and a second one
     from most of them (in-degree 70 + 40 > 64, so rows are split and the store cannot register its own structure)."""
