@@ -21,6 +21,28 @@ from . import compiled_ops, layer_fn
 from .graph import graph_for
 
 
+class _SplitCatWeight(torch.autograd.Function):
+    """linear.weight = [Wi | Wj | We] (models/layers.py:22) -> ([Wi ; Wj] stacked row-wise, We), two copies forward and
+    two backward.  The same thing written with torch.cat and slices costs a dozen small launches per step, backward
+    included, which is a fifth of a replayed step on a batch of molecules."""
+
+    @staticmethod
+    def forward(ctx, w, f):
+        h = w.size(0)
+        ctx.f = f
+        w_nodes = w[:, :2 * f].reshape(h, 2, f).transpose(0, 1).reshape(2 * h, f)   # one strided copy
+        return w_nodes, w[:, 2 * f:].contiguous()
+
+    @staticmethod
+    def backward(ctx, g_nodes, g_edge):
+        f = ctx.f
+        h = g_nodes.size(0) // 2
+        g = torch.empty((h, 2 * f + g_edge.size(1)), dtype=g_nodes.dtype, device=g_nodes.device)
+        g[:, :2 * f].view(h, 2, f).copy_(g_nodes.view(2, h, f).transpose(0, 1))
+        g[:, 2 * f:].copy_(g_edge)
+        return g, None
+
+
 class MPNNLayerCat(torch.nn.Module):
     def __init__(self, in_channels, edge_channels, out_channels):
         super().__init__()
@@ -29,14 +51,12 @@ class MPNNLayerCat(torch.nn.Module):
         self.linear_out = Linear(out_channels + in_channels, out_channels, bias=False)
 
     def forward(self, x, edge_index, edge_attr):
-        f = self.in_channels
-        w = self.linear.weight
         # [Wi ; Wj] stacked row-wise gives the [N, 2H] table (target half, source half) in one GEMM.
-        w_nodes = torch.cat([w[:, :f], w[:, f:2 * f]], dim=0)
+        w_nodes, w_edge = _SplitCatWeight.apply(self.linear.weight, self.in_channels)
         if torch.compiler.is_compiling():      # torch.compile(model), experiments/flickr_exp.py:30: one opaque operator
-            return compiled_ops.layer(x, edge_index, edge_attr, w_nodes, w[:, 2 * f:], self.linear_out.weight)
+            return compiled_ops.layer(x, edge_index, edge_attr, w_nodes, w_edge, self.linear_out.weight)
         graph = graph_for(edge_index, x.size(0))
-        return layer_fn.layer_forward(x, edge_attr, w_nodes, w[:, 2 * f:], self.linear_out.weight, graph)
+        return layer_fn.layer_forward(x, edge_attr, w_nodes, w_edge, self.linear_out.weight, graph)
 
 
 class MPNNLayerSum(torch.nn.Module):
