@@ -73,6 +73,34 @@ def test_layer_sum_at_benchmark_size_against_cpu_oracle_on_sampled_rows(n, e, ch
         assert torch.equal(a, b)
 
 
+def test_layer_cat_at_a_quarter_of_the_benchmark_size_against_the_cpu_oracle():
+    """MPNNLayerCat (models/layers.py:22,56 - the reference experiments' default form) on the 1 M-node / 25 M-edge graph:
+    relu(W [x_i | x_j | e]) = relu(Wi x_i + Wj x_j + We e), so the float64 oracle of the sum form with [Wi ; Wj] and We
+    is the oracle of the cat form, and the gradient of linear.weight is its pieces side by side."""
+    from mpnn_amd import MPNNLayerCat, synth
+    dev = torch.device("cuda:0")
+    n, e, H = 1_000_000, 25_000_000, 128
+    d = synth.powerlaw(dev, 0, n, e, H, 4)
+    x, ei, ea = d["x"], d["edge_index"], d["edge_attr"]
+    torch.manual_seed(1)
+    layer = MPNNLayerCat(H, 4, H).to(dev)
+    rows = S.sample_rows(ei, n, 1, 2000, hubs=2, seed=3)
+    gen = torch.Generator(device=dev).manual_seed(4)
+    gy_rows = torch.randn(rows.numel(), H, generator=gen, device=dev)
+    gy = torch.zeros(n, H, device=dev)
+    gy[rows] = gy_rows
+    xg = x.detach().requires_grad_(True)
+    y = layer(xg, ei, ea)
+    y.backward(gy)
+    w = layer.linear.weight.detach()
+    want = S.layer_sum_sparse_upstream(x, ei, ea, torch.cat([w[:, :H], w[:, H:2 * H]], 0), w[:, 2 * H:].contiguous(),
+                                       layer.linear_out.weight, rows, gy_rows)
+    gw = torch.cat([want["gw_fused"][:H], want["gw_fused"][H:], want["gw_edge"]], 1)
+    nodes = want["nodes"]
+    _check([("y[rows]", y.detach()[rows], want["y_rows"]), ("grad x[nodes]", xg.grad[nodes], want["gx"]),
+            ("grad linear", layer.linear.weight.grad, gw), ("grad linear_out", layer.linear_out.weight.grad, want["gw_out"])])
+
+
 @pytest.mark.parametrize("n,e,chunk", SIZES)
 def test_edge_operator_at_benchmark_size_with_dense_upstream_gradient(n, e, chunk):
     """The two edge passes alone (mpnn_aggregate_fwd, mpnn_aggregate_bwd_src_masked) with the dense upstream
