@@ -241,7 +241,7 @@ class MPGraph:
                 self.islands = Islands(ptr, count, largest, most_edges)
             if count > 0 and largest < ISLAND_GIVE_UP_NODES:
                 self._by_src = None
-                self._deferred = (src, dst, chunk, max_parts, status, ws)
+                self._deferred = (src, dst, chunk, max_parts, status, ws, src._version, dst._version)
                 return
             p1 = _build_items(self._by_dst, chunk, max_parts, status, ws)
             self._by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, False)
@@ -259,7 +259,11 @@ class MPGraph:
 
     def _complete(self) -> None:
         """Builds what a two-phase build left out: the work items of the destination view and the source view."""
-        src, dst, chunk, max_parts, status, ws = self._deferred
+        src, dst, chunk, max_parts, status, ws, v_src, v_dst = self._deferred
+        if (src._version, dst._version) != (v_src, v_dst):
+            # the destination view was sorted from the old contents: a source view of the new ones would not match it
+            raise RuntimeError("edge_index was modified in place after its graph structure was built; "
+                               "build a new structure (graph_for does, it keys on the tensor's version)")
         self._deferred = None
         p1 = _build_items(self._by_dst, chunk, max_parts, status, ws)
         self._by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, False)

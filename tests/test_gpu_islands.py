@@ -275,6 +275,21 @@ def test_islands_too_large_or_too_many_use_the_general_path(islands_on, monkeypa
     assert islands.plan_for(g, 11, 64, 4, False) is None
 
 
+def test_a_deferred_source_view_refuses_an_edge_list_that_changed(islands_on):
+    """The two-step build sorts the destination view first and the source view on demand; if edge_index was overwritten
+    in between, the second step raises instead of pairing views of two different edge lists."""
+    from mpnn_amd.graph import MPGraph
+    d = molecules(5, 40)
+    ei = d["edge_index"].to(DEV).clone()
+    g = MPGraph(ei, d["n"])
+    assert g.islands is not None and g._deferred is not None
+    ei[0, 0] = ei[0, 1]
+    with pytest.raises(RuntimeError, match="modified in place"):
+        g.by_src
+    g2 = MPGraph(ei, d["n"])
+    assert g2.by_src.rowptr.numel() == d["n"] + 1
+
+
 def test_padded_collated_batches_run_island_by_island(islands_on):
     """A fixed-capacity batch of GraphStore.collate: its graphs are the islands, the padding rows an edgeless tail;
     real rows equal the unpadded batch's bit for bit, parameter gradients too."""
