@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 13
+#define MPNN_ABI_VERSION 14
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -367,6 +367,9 @@ int32_t mpnn_egnn_bwd_src(const void* A, int64_t ldA, const void* B, int64_t ldB
  *   Y2 (optional, with emul [N,M]): second output Y2 = Y * emul written by the same epilogue
  *   (d aggr and d A = d aggr * cnt leave one GEMM together).  emul_kind: MPNN_F32 (float) or MPNN_U8 (one
  *   byte per entry, the counts of mpnn_aggregate_fwd); ldemul in elements of that kind.
+ *   addend (optional, [N,M], not together with Y2): Y = act(products + addend).  With it the update of
+ *   models/layers.py:69,140 becomes relu(P + aggr W_a^T), where P = x W_x^T left the projection's GEMM as extra
+ *   output columns (x [W_n ; W_x]^T): x is read once per forward instead of twice.
  *   Arithmetic: by default every float32 operand is split into three bfloat16 pieces and the products run on
  *   the bfloat16 matrix cores with float32 accumulation (six piece products per product; error against a
  *   float64 product no larger than the float32 matrix cores'); MPNN_GEMM=f32 in the environment selects the
@@ -386,8 +389,8 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
                          const float* W1, int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2,
                          const float* mask2, int64_t ldm2, const float* W2, int64_t ldw2, int32_t K2,
                          float* Y, int64_t ldy, const void* emul, int32_t emul_kind, int64_t ldemul,
-                         float* Y2, int64_t ldy2, int64_t N, int32_t M, int32_t relu, void* scratch,
-                         mpnn_stream_t stream);
+                         float* Y2, int64_t ldy2, const float* addend, int64_t ldadd, int64_t N, int32_t M,
+                         int32_t relu, void* scratch, mpnn_stream_t stream);
 int64_t mpnn_gemm_nt_scratch_bytes(int32_t M, int32_t K1, int32_t K2);
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K);
 int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t ldm,

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 MPNN_F32 = 0
 MPNN_BF16 = 1
 MPNN_U8 = 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -117,8 +117,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "mpnn_gemm_nt_f32": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
                                    c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int32,
-                                   c_void_p, c_int64, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_int64, c_int32,
-                                   c_int32, c_void_p, c_void_p]),
+                                   c_void_p, c_int64, c_void_p, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "mpnn_gemm_nt_scratch_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "mpnn_gemm_nt_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_int64, c_void_p,
                                     c_int64, c_int32, c_void_p, c_int64, c_void_p, c_int32, c_int64, c_void_p, c_int64,

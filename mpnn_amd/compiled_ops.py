@@ -49,7 +49,8 @@ def layer_fwd(x: Tensor, edge_index: Tensor, edge_attr: Tensor, w_nodes: Tensor,
 def _(x, edge_index, edge_attr, w_nodes, w_edge, w_out, train):
     n, h = x.size(0), w_out.size(0)
     y = x.new_empty((n, h))
-    ab = x.new_empty((n, 2 * h))
+    # the projection carries the x-part of the update as a third block of columns when x is read once (fused_x)
+    ab = x.new_empty((n, (3 if layer_fn.fused_x(x.dtype, x.size(1), h) else 2) * h))
     aggr = x.new_empty((n, h))
     cnt = x.new_empty((n if train else 0, h), dtype=torch.uint8)
     # exact counts of the rows longer than a byte can count: as many rows as the graph has such rows

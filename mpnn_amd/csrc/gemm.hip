@@ -44,9 +44,11 @@ struct NtArgs {
   const float* emul; int64_t ldemul;  // optional [N, M]: second output Y2 = Y * emul
   const uint8_t* emul8;               // the same factor stored as bytes (emul is null then)
   float* Y2; int64_t ldy2;
+  const float* C; int64_t ldc;        // optional [N, M]: added to the product before the activation
   int64_t N; int M;
   int relu;
   const char* wimg;   // optional: the weights split once per call into chunk images (k_split_weights)
+  int ws_staged;      // k_gemm_nt_ws: 16-byte stores through LDS patches (aligned rows, M % 4 == 0)
 };
 
 // Branch-free 4-float load at columns k..k+3 of a row of K floats.  The address is clamped into the row so
@@ -420,6 +422,17 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
         // whole tile inside the matrix: one running row pointer, the MT column tiles at immediate offsets
         float* p = a.Y + (row0 + wr * 32 + 4 * lh) * a.ldy + (m0 + wc * MT * 32 + li);
         const bool relu = a.relu != 0;
+        if (a.C) {   // uniform: the addend's rows are read in the same pattern, all of a tile column before its sums
+          const float* cp = a.C + (row0 + wr * 32 + 4 * lh) * a.ldc + (m0 + wc * MT * 32 + li);
+#pragma unroll
+          for (int t = 0; t < MT; ++t) {
+            float cv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cv[r] = cp[((r & 3) + 8 * (r >> 2)) * a.ldc + t * 32];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] += cv[r];
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
 #pragma unroll
@@ -440,6 +453,7 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
             const int64_t row = row0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (col < a.M && row < a.N) {
               float v = acc[t][r];
+              if (a.C) v += a.C[row * a.ldc + col];
               if (a.relu) v = v <= 0.f ? 0.f : v;
               a.Y[row * a.ldy + col] = v;
               if constexpr (WITH_Y2) {
@@ -484,13 +498,15 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt(NtArgs a) {
 
 // One block per (column block, 16-wide chunk): the chunk's weight rows as their three bfloat16 pieces, 96 bytes per
 // row in the order of an LDS row of k_gemm_nt's split form; rows and columns past the end are zeros.
-__global__ void __launch_bounds__(kBlock) k_split_weights(NtArgs a, char* __restrict__ out, int wrows) {
+// `pitch` = bytes per image row: 96 (payload only) or the 112 of an LDS row, pad included, for the kernel that copies
+// whole images into LDS with linear DMA pieces.
+__global__ void __launch_bounds__(kBlock) k_split_weights(NtArgs a, char* __restrict__ out, int wrows, int pitch) {
   const int nch0 = (a.seg[0].K + kSplitBK - 1) / kSplitBK;
   const int nch = nch0 + (a.nseg > 1 ? (a.seg[1].K + kSplitBK - 1) / kSplitBK : 0);
   const int cb = blockIdx.x / nch, c = blockIdx.x % nch;
   const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
   const int k0 = (c < nch0 ? c : c - nch0) * kSplitBK;
-  char* img = out + (int64_t)blockIdx.x * wrows * 96;
+  char* img = out + (int64_t)blockIdx.x * wrows * pitch;
   for (int idx = threadIdx.x; idx < wrows * (kSplitBK / 4); idx += kBlock) {
     const int r = idx / (kSplitBK / 4), q = idx % (kSplitBK / 4);
     const int m = cb * wrows + r, kk = k0 + q * 4;
@@ -499,8 +515,381 @@ __global__ void __launch_bounds__(kBlock) k_split_weights(NtArgs a, char* __rest
     uint2 pz[3];
     split4(v, pz);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(img + r * 96 + i * (kSplitBK * 2) + q * 8) = pz[i];
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(img + r * pitch + i * (kSplitBK * 2) + q * 8) = pz[i];
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The split form with the work divided between waves: a block is 8 waves, 4 PRODUCERS and 4 CONSUMERS, one of each
+// per SIMD, one block per CU.  Producers fetch X (a ring of 8 register sets: the loads run 8 k-chunks ahead of their
+// use), split it into its three bfloat16 pieces and write the pieces to LDS; consumers copy the chunk images of the
+// pre-split weights (k_split_weights, rows at the LDS pitch) from global memory straight into LDS with DMA loads
+// (no registers, no LDS store instructions), read fragments and issue matrix instructions - nothing else.
+// Measured with per-wave cycle counters (tools/ws_prof.py): while a consumer is not waiting at a barrier or storing
+// its tile it issues one v_mfma_f32_32x32x16_bf16 every 49 cycles, which is the rate a bare loop of that
+// instruction reaches on this chip (tools/mfma_probe.hip: 40 per microsecond and SIMD, 1.34 PFLOP/s over the chip -
+// not the 32 cycles of the data sheet); the rest of the time is the barrier per chunk (8-13 %), the epilogue and
+// the last, partly empty round of row steps.
+// LDS holds a ring of 3 stages (X tile 128 rows + W tile 64 NC rows, 112-byte rows); during iteration i the
+// consumers multiply chunk i out of registers that were filled from stage i % 3 during iteration i - 1, request
+// the fragments of chunk i + 1 and start the copy of weight image i + 2, while the producers write the X pieces of
+// chunk i + 2 into stage (i + 2) % 3; one block barrier per chunk.  A consumer wave owns 64 rows x 32 NC columns
+// (2 x NC matrix tiles: 6 + 3 NC fragment reads for 12 NC matrix instructions per chunk).  The (row step, k-chunk)
+// pairs of a block form one flat sequence as in k_gemm_nt.  Same piece products in the same order as k_gemm_nt:
+// the two kernels agree bit for bit.
+constexpr int kWsStages = 3;
+constexpr int kWsRound = 24;   // copies of the producers' loop body: register sets (8 or 4) x stages
+
+// Per-wave cycle counts of k_gemm_nt_ws for tools/ws_prof.py (built only with -DMPNN_WS_PROF): total, spent at
+// barriers, spent in the epilogue.
+#ifdef MPNN_WS_PROF
+__device__ long long* g_ws_prof = nullptr;
+#define WS_NOW() ((long long)__builtin_readcyclecounter())
+#define WS_SYNC() do { const long long t0_ = WS_NOW(); __syncthreads(); prof_wait += WS_NOW() - t0_; } while (0)
+#else
+#define WS_SYNC() __syncthreads()
+#endif
+
+// (stages + one 32 x 32 patch, pitch 36 floats, per consumer wave for the epilogue)
+template <int NC>
+constexpr int ws_lds_bytes() { return kWsStages * (kBN + 64 * NC) * kSplitRowB + 4 * 32 * 36 * 4; }
+
+template <int NC, bool MASKED>
+__global__ void __launch_bounds__(512, 1) k_gemm_nt_ws(NtArgs a) {
+  constexpr int BK = kSplitBK;
+  constexpr int WROWS = 64 * NC;
+  constexpr int ROWB = kSplitRowB;
+  constexpr int STAGEB = (kBN + WROWS) * ROWB;
+  constexpr int NPROD = 256;
+  constexpr int XQ = (kBN * (BK / 4)) / NPROD;          // float4 of X per producer thread and chunk (2)
+  constexpr int WIMG = WROWS * ROWB;                    // bytes of a weight chunk image, LDS row pitch included
+  constexpr int WPIECES = WIMG / 1024;                  // 1-KiB pieces of it: one DMA instruction of a wave each
+  static_assert(WIMG % 1024 == 0, "the weight image must be whole DMA pieces");
+  constexpr int D = MASKED ? 4 : 8;                     // register sets of the X ring (chunks in flight)
+  extern __shared__ float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.y * WROWS;
+  const int nch0 = (a.seg[0].K + BK - 1) / BK;
+  const int nch = nch0 + (a.nseg > 1 ? (a.seg[1].K + BK - 1) / BK : 0);
+  const int64_t nsteps_all = (a.N + kBN - 1) / kBN;
+  const int64_t my_steps = blockIdx.x < nsteps_all ? (nsteps_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  const int64_t total = my_steps * nch;
+  if (total == 0) return;   // uniform over the block
+#ifdef MPNN_WS_PROF
+  long long prof_wait = 0, prof_epi = 0;
+  const long long prof_t0 = WS_NOW();
+  auto prof_done = [&]() {
+    if (g_ws_prof && lane == 0) {
+      long long* o = g_ws_prof + ((int64_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wid) * 4;
+      o[0] = WS_NOW() - prof_t0; o[1] = prof_wait; o[2] = prof_epi; o[3] = total;
+    }
+  };
+#endif
+
+  if (wid >= 4) {
+    // ------------------------------------------------------------------------------------------ producers
+    const int pt = tid - 256;
+    float4 xr[D][XQ], mr[MASKED ? D : 1][XQ];
+    int xk[D], xK[D];
+    int64_t f_row0 = (int64_t)blockIdx.x * kBN;   // position of the next X fetch in the (row step, chunk) sequence
+    int f_c = 0;
+    auto fetch_x = [&](auto S) {
+      constexpr int st = decltype(S)::value;
+      const int c = f_c;
+      const int64_t row0 = f_row0;
+      if (++f_c == nch) { f_c = 0; f_row0 += (int64_t)gridDim.x * kBN; }
+      const NtSegment& sg = a.seg[c < nch0 ? 0 : 1];
+      const int k0 = (c < nch0 ? c : c - nch0) * BK;
+      const bool masked = MASKED && sg.mask != nullptr;
+      xk[st] = k0;
+      xK[st] = sg.K;
+      // uniform base + 32-bit lane offset; rows past the end re-read the last row (never stored), chunks past
+      // the end of the block's work re-read valid rows (never used): every load is issued unconditionally
+      const int64_t left = a.N - 1 - row0;
+      const int rt_max = left < kBN - 1 ? (left < 0 ? 0 : (int)left) : kBN - 1;
+      const int64_t rbase = row0 <= a.N - 1 ? row0 : a.N - 1;
+      const float* xb = sg.X + rbase * sg.ldx;
+      const float* mb = masked ? sg.mask + rbase * sg.ldm : kOnes;
+      const uint32_t ldx = (uint32_t)sg.ldx, ldm = masked ? (uint32_t)sg.ldm : 0u;
+      const bool tail = k0 + BK > sg.K;
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        const int idx = pt + NPROD * q;
+        int kk = k0 + (idx & 3) * 4;
+        if (tail) kk = kk < sg.K ? kk : sg.K - 4;
+        int rt = idx >> 2;
+        rt = rt < rt_max ? rt : rt_max;
+        xr[st][q] = *reinterpret_cast<const float4*>(xb + ((uint32_t)rt * ldx + (uint32_t)kk));
+        if constexpr (MASKED)
+          mr[st][q] = *reinterpret_cast<const float4*>(mb + ((uint32_t)rt * ldm + (masked ? (uint32_t)kk : 0u)));
+      }
+    };
+    auto stash = [&](auto S, int stage) {
+      constexpr int st = decltype(S)::value;
+      char* Xs = ldsb + stage * STAGEB;
+      const bool x_tail = xk[st] + BK > xK[st];   // uniform: only a row's last chunk masks
+#pragma unroll
+      for (int q = 0; q < XQ; ++q) {
+        const int idx = pt + NPROD * q;
+        float4 v = xr[st][q];
+        if (x_tail) v = select4(v, valid4(xk[st] + (idx & 3) * 4, xK[st], true));
+        if constexpr (MASKED) v = relu_mask4(v, mr[st][q]);
+        uint2 p[3];
+        split4(v, p);
+        char* dst = Xs + (idx >> 2) * ROWB + (idx & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(dst + i * (BK * 2)) = p[i];
+      }
+    };
+    // produce(s): chunk s goes from its register set s % D into stage s % 3, and the freed set starts the loads
+    // of chunk s + D
+    auto produce = [&](auto J, int64_t s) __attribute__((always_inline)) {
+      constexpr int j = decltype(J)::value;   // == s % 24
+      using XS = std::integral_constant<int, j % D>;
+      if (s < total) stash(XS{}, j % kWsStages);
+      fetch_x(XS{});
+    };
+    fetch_x(std::integral_constant<int, 0>{});
+    fetch_x(std::integral_constant<int, 1>{});
+    fetch_x(std::integral_constant<int, 2>{});
+    fetch_x(std::integral_constant<int, 3>{});
+    if constexpr (D > 4) {
+      fetch_x(std::integral_constant<int, 4>{});
+      fetch_x(std::integral_constant<int, 5>{});
+      fetch_x(std::integral_constant<int, 6>{});
+      fetch_x(std::integral_constant<int, 7>{});
+    }
+    produce(std::integral_constant<int, 0>{}, 0);
+    produce(std::integral_constant<int, 1>{}, 1);
+    WS_SYNC();
+    // All loads of the prologue land before the loop is entered (s_waitcnt vmcnt(0), once per block): the wait counts
+    // inside the loop are the worse of the two ways into it, and the compiler orders the prologue's loads as it
+    // likes - without this the first copy waits for almost the whole ring on every round.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // The loop always runs whole rounds of 24 copies (register sets x stages; the consumers execute the same
+    // number of barriers): a copy that could be skipped would give the compiler a path on which the loads just issued
+    // are the next ones used (skip -> back edge -> first copy), and it would then wait for the whole ring at the top
+    // of every round.  Chunks past the end are fetched from valid addresses and never written to LDS.
+    for (int64_t it = 0; it < total; it += kWsRound) {
+      produce(std::integral_constant<int, 2>{}, it + 2);
+      WS_SYNC();
+      produce(std::integral_constant<int, 3>{}, it + 3);
+      WS_SYNC();
+      produce(std::integral_constant<int, 4>{}, it + 4);
+      WS_SYNC();
+      produce(std::integral_constant<int, 5>{}, it + 5);
+      WS_SYNC();
+      produce(std::integral_constant<int, 6>{}, it + 6);
+      WS_SYNC();
+      produce(std::integral_constant<int, 7>{}, it + 7);
+      WS_SYNC();
+      produce(std::integral_constant<int, 8>{}, it + 8);
+      WS_SYNC();
+      produce(std::integral_constant<int, 9>{}, it + 9);
+      WS_SYNC();
+      produce(std::integral_constant<int, 10>{}, it + 10);
+      WS_SYNC();
+      produce(std::integral_constant<int, 11>{}, it + 11);
+      WS_SYNC();
+      produce(std::integral_constant<int, 12>{}, it + 12);
+      WS_SYNC();
+      produce(std::integral_constant<int, 13>{}, it + 13);
+      WS_SYNC();
+      produce(std::integral_constant<int, 14>{}, it + 14);
+      WS_SYNC();
+      produce(std::integral_constant<int, 15>{}, it + 15);
+      WS_SYNC();
+      produce(std::integral_constant<int, 16>{}, it + 16);
+      WS_SYNC();
+      produce(std::integral_constant<int, 17>{}, it + 17);
+      WS_SYNC();
+      produce(std::integral_constant<int, 18>{}, it + 18);
+      WS_SYNC();
+      produce(std::integral_constant<int, 19>{}, it + 19);
+      WS_SYNC();
+      produce(std::integral_constant<int, 20>{}, it + 20);
+      WS_SYNC();
+      produce(std::integral_constant<int, 21>{}, it + 21);
+      WS_SYNC();
+      produce(std::integral_constant<int, 22>{}, it + 22);
+      WS_SYNC();
+      produce(std::integral_constant<int, 23>{}, it + 23);
+      WS_SYNC();
+      produce(std::integral_constant<int, 0>{}, it + 24);
+      WS_SYNC();
+      produce(std::integral_constant<int, 1>{}, it + 25);
+      WS_SYNC();
+    }
+#ifdef MPNN_WS_PROF
+    prof_done();
+#endif
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------- consumers
+  const int li = lane & 31, lh = lane >> 5;
+  const int cr = wid >> 1, cc = wid & 1;
+  f32x16 acc[2][NC];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+  int64_t step = 0;
+  int c = 0;
+  // Fragments of chunk i + 1 are requested while chunk i is multiplied (the LDS ring holds chunk i + 1 complete
+  // since the barrier before iteration i), each into the registers of the fragment it replaces as soon as the last
+  // matrix instruction that reads those has been issued: the W fragments of a column tile after that tile's
+  // products, the X fragments of a row tile after its products with the last column tile.  Without this every
+  // chunk exposes one LDS round trip and the barrier (a third of the time).
+  bf16x8 av[2][3], bv[NC][3];
+  // per-lane parts of the fragment addresses; the stage offset is added once per chunk, tiles and pieces are
+  // immediate offsets.  Lane (li, lh) holds k = 8 lh .. 8 lh + 7 of row li of each piece: one 16-byte read per piece
+  const int a_lane = (cr * 64 + li) * ROWB + lh * 16;
+  const int b_lane = kBN * ROWB + (cc * NC * 32 + li) * ROWB + lh * 16;
+  auto read_a = [&](int i, const char* sb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) av[i][p] = *reinterpret_cast<const bf16x8*>(sb + a_lane + i * 32 * ROWB + p * (2 * BK));
+  };
+  auto read_b = [&](int t, const char* sb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bv[t][p] = *reinterpret_cast<const bf16x8*>(sb + b_lane + t * 32 * ROWB + p * (2 * BK));
+  };
+  auto epilogue = [&]() __attribute__((always_inline)) {
+    // C layout of a 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const int64_t row0 = (blockIdx.x + step * gridDim.x) * kBN + cr * 64;
+    ++step;
+    const bool relu = a.relu != 0;
+    if (a.ws_staged) {
+      // Every tile passes through the wave's own 32 x 32 patch of LDS (behind the stages) and leaves as 16 bytes per
+      // lane, 8 lanes to a 128-byte row segment: a quarter of the store instructions of the 4-byte form, which is
+      // what an epilogue costs (the host picks this when rows are 16-byte aligned and M % 4 == 0).
+      constexpr int PITCH = 36;   // floats: 9 sixteen-byte slots, conflict-free 16-byte reads
+      float* patch = reinterpret_cast<float*>(ldsb + kWsStages * STAGEB) + wid * (32 * PITCH);
+      const int prow = lane >> 3, pc4 = (lane & 7) * 4;   // a lane moves 4 columns of rows prow, prow + 8, ..
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            patch[((r & 3) + 8 * (r >> 2) + 4 * lh) * PITCH + li] = acc[i][t][r];
+            acc[i][t][r] = 0.f;
+          }
+          __builtin_amdgcn_wave_barrier();
+          const int col = m0 + (cc * NC + t) * 32 + pc4;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int pr = prow + 8 * k;
+            const int64_t row = row0 + i * 32 + pr;
+            float4 v = *reinterpret_cast<const float4*>(patch + pr * PITCH + pc4);
+            if (row < a.N && col < a.M) {
+              if (a.C) {
+                const float4 c4 = *reinterpret_cast<const float4*>(a.C + row * a.ldc + col);
+                v.x += c4.x; v.y += c4.y; v.z += c4.z; v.w += c4.w;
+              }
+              if (relu) {
+                v.x = v.x <= 0.f ? 0.f : v.x; v.y = v.y <= 0.f ? 0.f : v.y;
+                v.z = v.z <= 0.f ? 0.f : v.z; v.w = v.w <= 0.f ? 0.f : v.w;
+              }
+              *reinterpret_cast<float4*>(a.Y + row * a.ldy + col) = v;
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      return;
+    }
+    const int col0 = m0 + cc * NC * 32 + li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int t = 0; t < NC; ++t) {
+        const int col = col0 + t * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (col < a.M && row < a.N) {
+            float v = acc[i][t][r];
+            if (a.C) v += a.C[row * a.ldc + col];
+            if (relu) v = v <= 0.f ? 0.f : v;
+            a.Y[row * a.ldy + col] = v;
+          }
+          acc[i][t][r] = 0.f;
+        }
+      }
+  };
+  // The weight images go from global memory straight into LDS (no registers): every consumer wave copies its share
+  // of the 1-KiB pieces of chunk i + 2 at the start of iteration i, and the barrier at the end of the iteration
+  // (whose fence waits for the copies) publishes them; they are first read in iteration i + 1.
+  int w_c = 2 % nch;   // chunk of the next image to copy
+  auto copy_w = [&](int c, int stage) __attribute__((always_inline)) {
+    const char* img = a.wimg + ((int64_t)blockIdx.y * nch + c) * WIMG + lane * 16;
+    char* dst = ldsb + stage * STAGEB + kBN * ROWB;
+#pragma unroll
+    for (int j = 0; j < (WPIECES + 3) / 4; ++j) {
+      const int piece = wid + 4 * j;
+      if (piece < WPIECES)   // uniform over the wave
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + piece * 1024),
+                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+    }
+  };
+  copy_w(0, 0);
+  copy_w(1 % nch, 1);
+  WS_SYNC();
+  read_a(0, ldsb);
+  read_a(1, ldsb);
+#pragma unroll
+  for (int t = 0; t < NC; ++t) read_b(t, ldsb);
+  int stage = 0;
+  const int64_t rounds = (total + kWsRound - 1) / kWsRound * kWsRound;   // the producers' loop runs whole rounds
+  for (int64_t it = 0; it < rounds; ++it) {
+    if (it >= total) {   // uniform: only the barrier of a padding iteration
+      WS_SYNC();
+      continue;
+    }
+    stage = stage + 1 == kWsStages ? 0 : stage + 1;
+    const char* nb = ldsb + stage * STAGEB;   // the next chunk's stage
+    copy_w(w_c, stage + 1 == kWsStages ? 0 : stage + 1);   // chunk it + 2 (past the end: a valid image, never read)
+    w_c = w_c + 1 == nch ? 0 : w_c + 1;
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {   // smallest terms first
+        f32x16 v = acc[i][t];
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][2], bv[t][0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[t][2], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[t][1], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][1], bv[t][0], v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[t][1], v, 0, 0, 0);
+        acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i][0], bv[t][0], v, 0, 0, 0);
+        if (t == NC - 1) {
+          __builtin_amdgcn_sched_barrier(0);   // the reads below reuse the registers these products read
+          read_a(i, nb);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      read_b(t, nb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (++c == nch) {   // the row step is complete
+      c = 0;
+#ifdef MPNN_WS_PROF
+      const long long te = WS_NOW();
+      epilogue();
+      prof_epi += WS_NOW() - te;
+#else
+      epilogue();
+#endif
+    }
+    WS_SYNC();
+  }
+#ifdef MPNN_WS_PROF
+  prof_done();
+#endif
 }
 
 struct TnArgs {
@@ -1199,11 +1588,55 @@ static bool nt_aligned(const NtArgs& a) {
   return true;
 }
 
-template <int MT, int WC>
+// Room for the chunk images of the weights: column blocks of at most 256 rows in either kernel (k_gemm_nt,
+// k_gemm_nt_ws), whatever the block width chosen.
 static int64_t nt_scratch_bytes(int M, int K1, int K2) {
-  constexpr int WROWS = 32 * MT * WC;
   const int64_t nch = (K1 + kSplitBK - 1) / kSplitBK + (K2 + kSplitBK - 1) / kSplitBK;
-  return (int64_t)((M + WROWS - 1) / WROWS) * nch * WROWS * 96;
+  return (int64_t)((M + 255) / 256) * nch * 256 * kSplitRowB;   // (the padded rows of k_gemm_nt_ws's images)
+}
+
+// MPNN_GEMM_NT=old keeps every product on k_gemm_nt, MPNN_GEMM_NT=ws sends every product that k_gemm_nt_ws can
+// take to it (comparison).  Default: the widths k_gemm_nt would pad to 256 columns (129 .. 192).
+static int nt_wave_specialised() {
+  const char* e = getenv("MPNN_GEMM_NT");
+  return e && e[0] == 'o' ? 0 : (e && e[0] == 'w' ? 2 : 1);
+}
+
+template <int NC, bool MASKED>
+static void launch_nt_ws(dim3 grid, const NtArgs& a, hipStream_t stream) {
+  // more than 64 KiB of dynamic LDS needs the attribute, once per kernel and device, with that device current
+  static bool done[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_nt_ws<NC, MASKED>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, ws_lds_bytes<NC>()) == hipSuccess)
+      __atomic_store_n(&done[dev], true, __ATOMIC_RELEASE);
+    // on failure the launch below fails for want of LDS and the caller's launch check reports it
+  }
+  k_gemm_nt_ws<NC, MASKED><<<grid, 512, ws_lds_bytes<NC>(), stream>>>(a);
+}
+
+// The wave-specialised kernel takes the products it is built for: aligned operands, split arithmetic, one output,
+// room for the weight images, and enough columns to occupy four consumer waves.  Returns false otherwise.
+static bool try_nt_ws(NtArgs& a, bool aligned, hipStream_t stream) {
+  const int mode = nt_wave_specialised();
+  if (!aligned || !gemm_split() || a.Y2 || !a.wimg || !mode || a.M <= 64) return false;
+  const int nblk = (a.M + 255) / 256;
+  const int nc = ((a.M + nblk - 1) / nblk + 63) / 64;   // 2, 3 or 4
+  if (mode == 1 && nc != 3) return false;
+  const int wrows = 64 * nc;
+  const int nch = (a.seg[0].K + kSplitBK - 1) / kSplitBK + (a.nseg > 1 ? (a.seg[1].K + kSplitBK - 1) / kSplitBK : 0);
+  int64_t steps = (a.N + kBN - 1) / kBN;
+  const int64_t slots = 256 / nblk > 0 ? 256 / nblk : 1;   // one block per CU
+  dim3 grid((unsigned)(steps < slots ? steps : slots), nblk);
+  k_split_weights<<<nblk * nch, kBlock, 0, stream>>>(a, const_cast<char*>(a.wimg), wrows, kSplitRowB);
+  a.ws_staged = (a.M & 3) == 0 && (a.ldy & 3) == 0 && ((uintptr_t)a.Y & 15) == 0 &&
+                (!a.C || ((a.ldc & 3) == 0 && ((uintptr_t)a.C & 15) == 0));
+  const bool has_mask = a.seg[0].mask || (a.nseg > 1 && a.seg[1].mask);
+  if (nc <= 2) has_mask ? launch_nt_ws<2, true>(grid, a, stream) : launch_nt_ws<2, false>(grid, a, stream);
+  else if (nc == 3) has_mask ? launch_nt_ws<3, true>(grid, a, stream) : launch_nt_ws<3, false>(grid, a, stream);
+  else has_mask ? launch_nt_ws<4, true>(grid, a, stream) : launch_nt_ws<4, false>(grid, a, stream);
+  return true;
 }
 
 template <int MT, int WC>
@@ -1225,7 +1658,7 @@ static void launch_nt(NtArgs& a, bool aligned, hipStream_t stream) {
   const bool pre = split_form && a.wimg != nullptr && nt_presplit() && a.N >= (int64_t)128 * 1024;
   if (pre) {
     const int nch = (a.seg[0].K + kSplitBK - 1) / kSplitBK + (a.nseg > 1 ? (a.seg[1].K + kSplitBK - 1) / kSplitBK : 0);
-    k_split_weights<<<grid.y * nch, kBlock, 0, stream>>>(a, const_cast<char*>(a.wimg), WROWS);
+    k_split_weights<<<grid.y * nch, kBlock, 0, stream>>>(a, const_cast<char*>(a.wimg), WROWS, 96);
   } else {
     a.wimg = nullptr;
   }
@@ -1259,13 +1692,20 @@ static void launch_nt(NtArgs& a, bool aligned, hipStream_t stream) {
 
 using namespace mpnn;
 
+#ifdef MPNN_WS_PROF
+extern "C" int32_t mpnn_ws_prof_buffer(long long* buffer) {   // [blocks * 8 * 4] cycle counts, or null
+  MPNN_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mpnn::g_ws_prof), &buffer, sizeof(buffer)));
+  return MPNN_OK;
+}
+#endif
+
 extern "C" {
 
 int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int64_t ldm1, const float* W1,
                          int64_t ldw1, int32_t K1, const float* X2, int64_t ldx2, const float* mask2, int64_t ldm2,
                          const float* W2, int64_t ldw2, int32_t K2, float* Y, int64_t ldy, const void* emul,
-                         int32_t emul_kind, int64_t ldemul, float* Y2, int64_t ldy2, int64_t N, int32_t M,
-                         int32_t relu, void* scratch, mpnn_stream_t stream) {
+                         int32_t emul_kind, int64_t ldemul, float* Y2, int64_t ldy2, const float* addend,
+                         int64_t ldadd, int64_t N, int32_t M, int32_t relu, void* scratch, mpnn_stream_t stream) {
   if (emul_kind != MPNN_F32 && emul_kind != MPNN_U8) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: emul_kind %d", emul_kind);
   if (N < 0 || M < 1 || K1 < 1 || K2 < 0) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: bad sizes");
   if (N == 0) return MPNN_OK;
@@ -1281,9 +1721,15 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
   a.emul = emul_kind == MPNN_F32 ? static_cast<const float*>(emul) : nullptr;
   a.emul8 = emul_kind == MPNN_U8 ? static_cast<const uint8_t*>(emul) : nullptr;
   a.N = N; a.M = M; a.relu = relu;
+  if (addend && (ldadd < M || Y2)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: addend needs ldadd >= M and no second output");
+  a.C = addend; a.ldc = ldadd; a.ws_staged = 0;
   if (scratch && ((uintptr_t)scratch & 15)) return fail(MPNN_E_INVALID, "mpnn_gemm_nt_f32: scratch must be 16-byte aligned");
   a.wimg = static_cast<const char*>(scratch);
   const bool aligned = nt_aligned(a);
+  if (try_nt_ws(a, aligned, stream)) {
+    MPNN_LAUNCH_CHECK("k_gemm_nt_ws");
+    return MPNN_OK;
+  }
   if (M <= 32) launch_nt<1, 1>(a, aligned, stream);
   else if (M <= 64) launch_nt<2, 1>(a, aligned, stream);
   else if (M <= 128) launch_nt<4, 1>(a, aligned, stream);
@@ -1294,10 +1740,7 @@ int32_t mpnn_gemm_nt_f32(const float* X1, int64_t ldx1, const float* mask1, int6
 
 int64_t mpnn_gemm_nt_scratch_bytes(int32_t M, int32_t K1, int32_t K2) {
   if (M < 1 || K1 < 1 || K2 < 0) return -1;
-  if (M <= 32) return nt_scratch_bytes<1, 1>(M, K1, K2);
-  if (M <= 64) return nt_scratch_bytes<2, 1>(M, K1, K2);
-  if (M <= 128) return nt_scratch_bytes<4, 1>(M, K1, K2);
-  return nt_scratch_bytes<4, 2>(M, K1, K2);
+  return nt_scratch_bytes(M, K1, K2);
 }
 
 int64_t mpnn_gemm_tn_scratch_floats(int64_t N, int32_t M, int32_t K) {   // K = K + K2 of the call

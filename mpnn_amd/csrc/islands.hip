@@ -159,8 +159,9 @@ __global__ void __launch_bounds__(kScanBlock) k_islands_build(const int32_t* __r
     const int incl = block_scan_inclusive(top, sm, imax);
     totals[t] = incl;
     __syncthreads();
-    int before = t > 0 ? totals[t - 1] : -1;   // max over threads < t
+    const int before0 = t > 0 ? totals[t - 1] : -1;   // max over threads < t (kept: totals is rewritten below)
     __syncthreads();
+    int before = before0;
     int cuts = 0;
     for (int r = r0; r < r1; ++r) {
       before = imax(before, hi[r]);
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(kScanBlock) k_islands_build(const int32_t* __r
     }
     upto = block_scan_inclusive(cuts, sm, iadd);
     int pos = upto - cuts;   // cuts of the threads before this one
-    before = t > 0 ? totals[t - 1] : -1;
+    before = before0;
     for (int r = r0; r < r1; ++r) {
       before = imax(before, hi[r]);
       if (before <= r && lo[r] > r) island_ptr[++pos] = r + 1;

@@ -62,16 +62,18 @@ def _emul_kind(emul) -> int:
     raise TypeError(f"emul must be float32 or uint8, got {emul.dtype}")
 
 
-def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=None, out2=None) -> torch.Tensor:
-    """act(x1 @ w1^T [+ x2 @ w2^T]); maskI > 0 selects the entries of xI that are used.
+def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=None, out2=None, add=None,
+            out=None) -> torch.Tensor:
+    """act(x1 @ w1^T [+ x2 @ w2^T] [+ add]); maskI > 0 selects the entries of xI that are used.
 
     With ``emul`` [N, M] (float32 or uint8) and ``out2`` (a [N, M] view with unit column stride) the epilogue also
-    writes out2 = result * emul."""
+    writes out2 = result * emul.  ``add`` is a [N, M] matrix (unit column stride) added before the activation;
+    ``out`` a [N, M] view to write into instead of a new matrix."""
     lib = _lib.load()
     x1, w1 = _rows(x1), _rows(w1)
     n, k1 = x1.shape
     m = w1.size(0)
-    y = torch.empty((n, m), dtype=torch.float32, device=x1.device)
+    y = torch.empty((n, m), dtype=torch.float32, device=x1.device) if out is None else out
     if x2 is not None:
         x2, w2 = _rows(x2), _rows(w2)
     mask1 = _rows(mask1) if mask1 is not None else None
@@ -85,7 +87,7 @@ def gemm_nt(x1, w1, x2=None, w2=None, mask1=None, mask2=None, relu=False, emul=N
         _ld(mask2), _lib.ptr(w2), _ld(w2),
         x2.size(1) if x2 is not None else 0,
         _lib.ptr(y), _ld(y), _lib.ptr(emul), _emul_kind(emul), _ld(emul), _lib.ptr(out2),
-        _ld(out2), n, m, 1 if relu else 0, _lib.ptr(wimg),
+        _ld(out2), _lib.ptr(add), _ld(add), n, m, 1 if relu else 0, _lib.ptr(wimg),
         _lib.stream_handle(x1.device)),
         "mpnn_gemm_nt_f32")
     return y

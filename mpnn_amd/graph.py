@@ -260,6 +260,11 @@ class MPGraph:
     def _complete(self) -> None:
         """Builds what a two-phase build left out: the work items of the destination view and the source view."""
         src, dst, chunk, max_parts, status, ws, v_src, v_dst = self._deferred
+        if torch.cuda.is_current_stream_capturing():
+            # the build ends with a host read of the item counts, which a capture cannot hold
+            raise RuntimeError("the graph structure of this edge_index is only half built (destination view and "
+                               "islands) and a kernel of the general path asks for the rest during a HIP-graph "
+                               "capture; call MPGraph.complete() (or run the step once) before capturing")
         if (src._version, dst._version) != (v_src, v_dst):
             # the destination view was sorted from the old contents: a source view of the new ones would not match it
             raise RuntimeError("edge_index was modified in place after its graph structure was built; "
@@ -268,6 +273,13 @@ class MPGraph:
         p1 = _build_items(self._by_dst, chunk, max_parts, status, ws)
         self._by_src, p2 = _build_csr(src, dst, self.num_src, self.num_dst, chunk, max_parts, False)
         _finish([self._by_dst, self._by_src], [p1, p2])
+
+    def complete(self) -> "MPGraph":
+        """Finishes a two-phase build now (work items, source view), e.g. before a HIP-graph capture whose kernels
+        may take the general path.  A no-op on a fully built structure."""
+        if self._deferred is not None:
+            self._complete()
+        return self
 
     @property
     def by_dst(self) -> CSR:

@@ -10,6 +10,16 @@ sequence of library calls, so that nothing between them needs an elementwise pas
              gAB[:, H:], gWe = edge backward(ga)            edge pass over the transpose
              gx   = (gy * [y>0]) Wx + gAB Wn                NT GEMM, 2 segments (no separate add)
              gWn  = gAB^T x ; gW_out = (gy*[y>0])^T [x | aggr]   TN GEMMs
+
+Wide inputs (F >= 2 H, float32: Flickr's 500 features against 64 channels) read x ONCE per direction instead of
+twice - the reference reads it at models/layers.py:104 and again at :140:
+
+  forward    [A | B | P] = x [Wn ; Wx]^T                    one NT GEMM, 3 H columns
+             y = relu(P + aggr Wa^T)                        NT GEMM over H columns with P as its addend
+  backward   gz = gy * [y>0], gW_out[:, F:] = gz^T aggr     small TN GEMM; gz lands in columns 2H.. of [gA | gB | gz]
+             ga, gA, gB, gWe as above
+             gx = [gA | gB | gz] [Wn ; Wx]                  one NT GEMM, K = 3 H
+             [gWn ; gW_out[:, :F]] = [gA | gB | gz]^T x     one TN GEMM
 """
 from __future__ import annotations
 
@@ -18,6 +28,12 @@ import torch
 from . import islands, ops
 from .dense import gemm_nt, gemm_nt_bf16, gemm_tn, gemm_tn_bf16
 from .graph import MPGraph
+
+
+def fused_x(dtype, f: int, h: int) -> bool:
+    """Whether the layer reads x once per direction (projection and the x-part of the update as one product).  It
+    costs one more [N, H] matrix written and read, so it pays when x is at least twice as wide as that."""
+    return dtype == torch.float32 and f >= 2 * h and f % 4 == 0 and h % 4 == 0
 
 
 def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: bool):
@@ -36,12 +52,19 @@ def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: boo
         y, _, saved = islands.forward(plan, graph, x, edge_attr, w_nodes, w_edge, w_out)
         n = x.size(0)
         cnt = (torch.empty((n, h), dtype=torch.uint8, device=x.device), None) if want else None
-        return y, x.new_empty((n, 2 * h)), x.new_empty((n, h)), cnt, None, saved[1]
-    ab = gemm_nt_bf16(x, w_nodes.contiguous()) if bf else gemm_nt(x, w_nodes)
-    a, b = ab[:, :h], ab[:, h:]
+        width = (3 if fused_x(x.dtype, f, h) else 2) * h      # the shape the general path would return
+        return y, x.new_empty((n, width)), x.new_empty((n, h)), cnt, None, saved[1]
+    fused = fused_x(x.dtype, f, h) and x.data_ptr() % 16 == 0
+    if fused:
+        ab = gemm_nt(x, torch.cat([w_nodes, w_out[:, :f]], dim=0))     # [A | B | P], P = x Wx^T
+    else:
+        ab = gemm_nt_bf16(x, w_nodes.contiguous()) if bf else gemm_nt(x, w_nodes)
+    a, b = ab[:, :h], ab[:, h:2 * h]
     ea_s, ea_t = ops._prepare(a, b, edge_attr, w_edge, graph)
     aggr, cnt, maskbits = ops._run_forward(a, b, ea_s, w_edge.contiguous(), graph.by_dst, graph, want)
-    if bf:
+    if fused:
+        y = gemm_nt(aggr, w_out[:, f:], add=ab[:, 2 * h:], relu=True)
+    elif bf:
         y = gemm_nt_bf16(x, w_out[:, :f].contiguous(), aggr, w_out[:, f:].contiguous(), relu=True)
     else:
         y = gemm_nt(x, w_out[:, :f], aggr, w_out[:, f:], relu=True)
@@ -68,6 +91,26 @@ def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_ou
     wt_out = w_out.t().contiguous()                   # [F+H, H]
     g_ab = torch.empty_like(ab)
     g_wout = torch.empty((h, f + h), dtype=gy.dtype, device=gy.device) if need_wout else None
+    if ab.size(1) == 3 * h:    # forward_impl read x once (fused_x): so does the backward
+        gz = g_ab[:, 2 * h:]
+        if need_wout and all(t.data_ptr() % 16 == 0 for t in (gy, y, aggr)):
+            gemm_tn(gy, aggr, mask=y, out=g_wout[:, f:], g_out=gz)
+        else:
+            gz.copy_(torch.ops.aten.threshold_backward(gy, y, 0))
+            if need_wout:
+                gemm_tn(gz, aggr, out=g_wout[:, f:])
+        ga = gemm_nt(gz, wt_out[f:], emul=cnt[0], out2=g_ab[:, :h])
+        ops.count_fixup(ga, cnt, graph.by_dst, g_ab[:, :h])
+        g_we = ops._run_backward_src(ab[:, :h], ab[:, h:2 * h], ga, ea_t, w_edge, graph.by_src, graph,
+                                     g_ab[:, h:2 * h], maskbits)
+        gx = gemm_nt(g_ab[:, :2 * h], w_nodes.t().contiguous(), gz, wt_out[:f]) if need_x else None
+        g_wn = None
+        if need_wn or need_wout:
+            g_cat = gemm_tn(g_ab, x)                  # [gWn ; gW_out[:, :F]]
+            g_wn = g_cat[:2 * h] if need_wn else None
+            if need_wout:
+                g_wout[:, :f] = g_cat[2 * h:]
+        return gx, g_wn, g_we if need_we else None, g_wout
     if bf:
         # gz = gy * [y > 0] is a by-product of the first weight-gradient product (whole 256-byte rows)
         if g_wout is not None:

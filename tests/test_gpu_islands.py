@@ -58,13 +58,17 @@ def molecules(seed, count, max_nodes=29, fe=4, f=11, dense=False):
                 pos=torch.randn(n, 3, generator=g), batch=torch.repeat_interleave(torch.arange(count), sizes), n=n)
 
 
-@pytest.mark.parametrize("case", ["molecules", "chain", "one-island", "no-edges", "qm9"])
+@pytest.mark.parametrize("case", ["molecules", "molecules-3000", "molecules-12000", "chain", "one-island", "no-edges",
+                                  "qm9"])
 def test_islands_match_the_oracle(islands_on, case):
     from mpnn_amd import synth
     from mpnn_amd.graph import MPGraph
-    if case == "molecules":
-        d = molecules(1, 300)
+    if case.startswith("molecules"):
+        # 3,000 / 12,000 molecules are 45 / 180 thousand nodes: more than 32 rows per thread of the one-block search,
+        # which then walks its rows in memory instead of registers
+        d = molecules(1, int(case.split("-")[1]) if "-" in case else 300)
         ei, n = d["edge_index"], d["n"]
+        assert ("-" not in case) or n > 32768
     elif case == "chain":            # consecutive nodes joined: one island although every edge is short
         n = 5000
         ei = torch.stack([torch.arange(n - 1), torch.arange(1, n)])

@@ -671,6 +671,49 @@ def test_gemm_nt_on_big_matrices(k1, k2, m, relu, masked, second, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,k1,k2,m,relu,masked,add", [
+    (89_250, 500, 0, 192, False, False, False),   # Flickr layer 1: projection with the update's x-part as extra columns
+    (89_250, 128, 64, 500, False, False, False),  # its input gradient: two segments, two column blocks
+    (20_001, 500, 0, 128, False, False, False),   # ragged last row step, ragged last k-chunk
+    (9_000, 64, 0, 64, True, False, True),        # update from the projected part: relu(P + aggr Wa^T), narrow kernel
+    (9_000, 64, 0, 128, True, False, True),       # the same through the wide kernel
+    (30_000, 128, 128, 256, True, True, False),   # mask on the first operand
+    (5_000, 36, 0, 320, False, True, True),       # two column blocks of 192, 20 columns past the end
+    (777, 16, 0, 100, True, False, True),         # less than one block per CU, columns past the end
+    (100, 500, 64, 65, False, False, False),
+])
+def test_gemm_nt_wide_products(n, k1, k2, m, relu, masked, add, monkeypatch):
+    """Products of more than 64 columns can run on the kernel that divides the work between producer and consumer
+    waves (k_gemm_nt_ws; by default those of 129 .. 192 columns do): float32 rounding level of the float64 product, bit for bit what k_gemm_nt gives (same piece
+    products in the same order), with an addend, a relu, an operand mask and ragged edges in rows, columns and k."""
+    from mpnn_amd.dense import gemm_nt
+    g = torch.Generator().manual_seed(n + m)
+    x1, x2 = torch.randn(n, k1, generator=g), (torch.randn(n, k2, generator=g) if k2 else None)
+    w = torch.randn(m, k1 + k2, generator=g) / (k1 + k2) ** 0.5
+    mask = torch.randn(n, k1, generator=g) if masked else None
+    c = torch.randn(n, m + 3, generator=g)[:, :m] if add else None     # a view: leading dimension above M
+    ref = (x1.double() * (mask > 0) if masked else x1.double()) @ w[:, :k1].double().t()
+    if k2:
+        ref = ref + x2.double() @ w[:, k1:].double().t()
+    if add:
+        ref = ref + c.double()
+    if relu:
+        ref = ref.relu()
+    cu = lambda t: t.cuda() if t is not None else None
+    wd = w.cuda()
+    out = {}
+    for form in ("ws", "old"):
+        monkeypatch.setenv("MPNN_GEMM_NT", form)
+        wide = torch.full((n, m + 5), 7.0, device="cuda")
+        y = gemm_nt(cu(x1), wd[:, :k1], cu(x2), wd[:, k1:] if k2 else None, mask1=cu(mask), relu=relu, add=cu(c),
+                    out=wide[:, :m])
+        assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-6, form
+        assert bool((wide[:, m:] == 7.0).all()), "columns beside the output were written"
+        out[form] = y.clone()
+    assert torch.equal(out["ws"], out["old"])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,k,m", [(5000, 64, 7), (89_250, 64, 7), (4100, 128, 19)])
 def test_node_level_head_matches_torch_linear(n, k, m):
     """dense.head on a tall input: output, input gradient, weight gradient and bias gradient (the column sums that come
