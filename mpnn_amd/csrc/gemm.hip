@@ -1158,7 +1158,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn(TnArgs a) {
 // the group ends up with 16 consecutive columns x 4 rows.  Lane half h takes rows 8h .. 8h + 7 of the slab in two
 // reads, which is the operand layout of v_mfma_f32_32x32x16_bf16.  The multiply loop has no VALU work left.
 constexpr int kTrRows = 16;
-constexpr int kTrPitch = 128 * 2 + 32;            // bytes; 4 consecutive rows start 8 banks apart
+constexpr int kTrPitch = 128 * 2 + 64;            // bytes; 4 consecutive rows start 16 banks apart: the 64-byte row pieces of
+                                                  // a transposed read then fall on disjoint banks
 constexpr int kTrPlane = kTrRows * kTrPitch;      // one piece of one matrix
 constexpr int kTrStage = 6 * kTrPlane;            // 3 pieces of G, 3 pieces of X
 
@@ -1327,6 +1328,166 @@ __global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr(TnArgs a) {
     }
   };
   put(0, acc0); put(1, acc1); put(2, acc2); put(3, acc3);
+}
+
+// The same kernel with an output tile of 192 x 128 (wave (wm, wk) owns 96 x 64: 3 x 2 matrix tiles) for weight
+// gradients of 129 .. 192 rows - [gA | gB | gz]^T x of a layer with 64 hidden channels.  With 128-row tiles such a
+// product pads to 256 rows: a third more matrix instructions, and X is read once per row tile.  Unmasked, aligned.
+constexpr int kTr192PitchG = 192 * 2 + 64;                       // bytes; 4 consecutive rows start 16 banks apart
+constexpr int kTr192PlaneG = kTrRows * kTr192PitchG;
+constexpr int kTr192Stage = 3 * kTr192PlaneG + 3 * kTrPlane;      // 3 pieces of G (192 wide), 3 pieces of X (128 wide)
+
+__global__ void __launch_bounds__(kBlock, 2) k_gemm_tn_tr192(TnArgs a) {
+  constexpr int D = 3;   // register sets of the slab ring (a fourth spills)
+  extern __shared__ float lds_f[];
+  char* const lds = reinterpret_cast<char*>(lds_f);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = (wid >> 1) * 96, wk = (wid & 1) * 64;
+  const TnTile xt = tn_tile(a);
+  const int m0 = blockIdx.y * 192, k0 = xt.k0;
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // a thread moves 3 float4 of G (rows (tid + 256 q) / 48, 48 float4 to a row) and 2 of X per slab
+  const int xpr = tid >> 5, xpc = (tid & 31) * 4;
+  int gpr[3], gpc[3];
+  uint32_t gcol[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int idx = tid + kBlock * q;
+    gpr[q] = idx / 48;
+    gpc[q] = (idx % 48) * 4;
+    gcol[q] = m0 + gpc[q] < a.M ? m0 + gpc[q] : a.M - 4;
+  }
+  const uint32_t xc = k0 + xpc < xt.K ? k0 + xpc : xt.K - 4;
+  const bool cols_full = m0 + 192 <= a.M && k0 + 128 <= xt.K;
+  float4 gr[D][3], xr[D][2];
+  auto fetch = [&](auto S, int64_t n0) {   // scalar slab base + 32-bit lane offsets, every load unconditional
+    constexpr int st = decltype(S)::value;
+    const int64_t left = a.N - 1 - n0;
+    const int rt_max = left < kTrRows - 1 ? (left < 0 ? 0 : (int)left) : kTrRows - 1;
+    const int64_t rbase = n0 < a.N ? n0 : a.N - 1;
+    const float* gb = a.G + rbase * a.ldg;
+    const float* xb = xt.X + rbase * xt.ldx;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const uint32_t r = gpr[q] < rt_max ? gpr[q] : rt_max;
+      gr[st][q] = *reinterpret_cast<const float4*>(gb + (r * (uint32_t)a.ldg + gcol[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t r = xpr + 8 * q < rt_max ? xpr + 8 * q : rt_max;
+      xr[st][q] = *reinterpret_cast<const float4*>(xb + (r * (uint32_t)xt.ldx + xc));
+    }
+  };
+  auto stash = [&](auto S, int buf, int64_t nslab) {
+    constexpr int st = decltype(S)::value;
+    const bool full = cols_full && nslab + kTrRows <= a.N;        // uniform: nothing to zero
+    char* base = lds + buf * kTr192Stage;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float4 g = gr[st][q];
+      if (!full) g = select4(g, valid4(m0 + gpc[q], a.M, nslab + gpr[q] < a.N));   // exact zeros past the end
+      uint2 gp[3];
+      split4(g, gp);
+      char* dst = base + gpr[q] * kTr192PitchG + gpc[q] * 2;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(dst + i * kTr192PlaneG) = gp[i];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = xpr + 8 * q;
+      float4 x = xr[st][q];
+      if (!full) x = select4(x, valid4(k0 + xpc, xt.K, nslab + r < a.N));
+      uint2 xp[3];
+      split4(x, xp);
+      char* dst = base + 3 * kTr192PlaneG + r * kTrPitch + xpc * 2;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) *reinterpret_cast<uint2*>(dst + i * kTrPlane) = xp[i];
+    }
+  };
+  // this lane's address inside a 32-column tile of a piece plane (see k_gemm_tn_tr)
+  const int s16 = lane & 15;
+  const int col_off = (16 * ((lane >> 4) & 1) + 4 * (s16 & 3)) * 2;
+  const int row_sel = 8 * lh + (s16 >> 2);
+  auto read_g = [&](const char* p) {   // rows +0..3 and +4..7 of the lane's 8, G pitch
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4_ptr)(p + 4 * kTr192PitchG));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto multiply = [&](int buf) __attribute__((always_inline)) {
+    const char* gbase = lds + buf * kTr192Stage + row_sel * kTr192PitchG + col_off + wm * 2;
+    const char* xbase = lds + buf * kTr192Stage + 3 * kTr192PlaneG + row_sel * kTrPitch + col_off + wk * 2;
+    bf16x8 ap[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) ap[i][p] = read_g(gbase + p * kTr192PlaneG + i * 64);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 bp[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bp[p] = read_tr8(xbase + p * kTrPlane + j * 64);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {   // smallest terms first
+        f32x16 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][2], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][1], bp[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[1], c, 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap[i][0], bp[0], c, 0, 0, 0);
+      }
+    }
+  };
+
+  const int64_t step = (int64_t)gridDim.x * kTrRows;
+  const int64_t first = (int64_t)blockIdx.x * kTrRows;
+  const int64_t total = first < a.N ? (a.N - first + step - 1) / step : 0;   // slabs of this block
+  auto body = [&](auto S, int64_t it) __attribute__((always_inline)) {
+    constexpr int st = decltype(S)::value;   // == it % D: the set slab `it` left when it was stashed
+    using Next = std::integral_constant<int, (st + 1) % D>;
+    const int64_t n0 = first + it * step;
+    const int buf = (int)(it & 1);
+    fetch(S, n0 + D * step);
+    multiply(buf);
+    if (it + 1 < total) stash(Next{}, buf ^ 1, n0 + step);
+    __syncthreads();
+  };
+  if (total > 0) {   // uniform over the block
+    fetch(std::integral_constant<int, 0>{}, first);
+    fetch(std::integral_constant<int, 1>{}, first + step);
+    fetch(std::integral_constant<int, 2>{}, first + 2 * step);
+    stash(std::integral_constant<int, 0>{}, 0, first);
+    __syncthreads();
+    for (int64_t it = 0; it < total; it += D) {
+      body(std::integral_constant<int, 0>{}, it);
+      if (it + 1 < total) body(std::integral_constant<int, 1>{}, it + 1);
+      if (it + 2 < total) body(std::integral_constant<int, 2>{}, it + 2);
+    }
+  }
+  const int ktot = a.K + a.K2;
+  float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int cl = k0 + wk + 32 * j + li;   // column inside the tile's matrix
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < a.M && cl < xt.K) out[(int64_t)row * ktot + (xt.kout0 - k0) + cl] = acc[i][j][r];
+      }
+    }
 }
 
 // Two output tiles per block of 8 waves, sharing one operand slab in LDS: PAIR_K = one 128-row tile of G^T
@@ -1530,7 +1691,8 @@ __global__ void __launch_bounds__(kBlock) k_sum_partials(const float* __restrict
 // written and re-read stay small next to the operands (8 was 10-20 % slower on matrices of 30-90 thousand rows,
 // whose walkers then cover half the chip; 2 is no faster than 4).
 static int tn_slabs(int64_t N, int M, int K) {
-  const int tiles = ((M + 127) / 128) * ((K + 127) / 128);
+  const int mtiles = M > 128 && M <= 192 ? 1 : (M + 127) / 128;   // (k_gemm_tn_tr192 takes 129 .. 192 rows as one tile)
+  const int tiles = mtiles * ((K + 127) / 128);
   int64_t slabs = 512 / tiles;
   const int64_t need = ((N + 31) / 32 + 3) / 4;   // in 32-row units whatever the kernel's slab height
   if (slabs > need) slabs = need;
@@ -1772,6 +1934,18 @@ int32_t mpnn_gemm_tn_f32(const float* G, int64_t ldg, const float* mask, int64_t
     return fail(MPNN_E_INVALID, "mpnn_gemm_tn_f32: Gout needs 16-byte aligned operands and ldgo >= M");
   dim3 grid(slabs, (M + 127) / 128, ztiles);
   auto go = [&](auto kern) { kern<<<grid, kBlock, 0, stream>>>(a); };
+  // 129 .. 192 rows: one 192-row tile instead of two of 128 (MPNN_GEMM_TN=single keeps the 128-row tiles)
+  if (aligned && gemm_split() && !tn_lds_split() && tn_pairs() && !mask && !Gout && M > 128 && M <= 192 &&
+      N < ((int64_t)1 << 19)) {
+    static bool done[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !__atomic_load_n(&done[dev], __ATOMIC_ACQUIRE)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn_tr192), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              2 * kTr192Stage) == hipSuccess)
+        __atomic_store_n(&done[dev], true, __ATOMIC_RELEASE);
+    }
+    k_gemm_tn_tr192<<<dim3(slabs, 1, ztiles), kBlock, 2 * kTr192Stage, stream>>>(a);
+  } else
   // Pairing pays once a block walks many slabs (it halves the traffic of the shared operand); on short matrices
   // the 8-wave blocks' start-up and barriers cost more than the re-read, which the caches absorb there.
   if (aligned && gemm_split() && !tn_lds_split() && tn_pairs() && (ztiles > 1 || grid.y > 1) && N >= ((int64_t)1 << 19)) {

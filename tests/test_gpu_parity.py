@@ -576,6 +576,24 @@ def test_gemm_tn(n, m, k, dev):
     assert torch.equal(again, got.contiguous()), "weight gradient is not bitwise reproducible"
 
 
+@pytest.mark.parametrize("n,m,k,k2", [(89_250, 192, 500, 0), (20_011, 192, 128, 64), (3_000, 132, 36, 0), (500, 160, 500, 4)])
+def test_gemm_tn_with_129_to_192_rows(n, m, k, k2, dev, monkeypatch):
+    """Weight gradients of 129 .. 192 rows ([gA | gB | gz]^T x of a 64-channel layer) take one 192-row output tile:
+    float64 product at float32 rounding level, reproducible, equal to rounding with the 128-row tiles."""
+    from mpnn_amd.dense import gemm_tn
+    gen = torch.Generator().manual_seed(n + m)
+    g, x = torch.randn(n, m, generator=gen).to(dev), torch.randn(n, k, generator=gen).to(dev)
+    x2 = torch.randn(n, k2, generator=gen).to(dev) if k2 else None
+    want = g.double().cpu().t() @ (torch.cat([x, x2], 1) if k2 else x).double().cpu()
+    wide = torch.zeros(m, k + k2 + 4, device=dev)
+    got = gemm_tn(g, x, x2=x2, out=wide[:, :k + k2])
+    assert_close(got, want, RTOL32, what="gemm_tn 192-row tile")
+    assert float(wide[:, k + k2:].abs().sum()) == 0.0
+    assert torch.equal(gemm_tn(g, x, x2=x2), got.contiguous()), "not reproducible"
+    monkeypatch.setenv("MPNN_GEMM_TN", "single")
+    assert_close(gemm_tn(g, x, x2=x2), want, RTOL32, what="gemm_tn 128-row tiles")
+
+
 # the last two are long enough (>= 2^19 rows) for the kernel that computes two tiles per block, one with an odd tile count
 @pytest.mark.parametrize("n,m,k,k2", [(5000, 128, 128, 128), (3001, 64, 500, 64), (700, 16, 11, 16), (2048, 256, 132, 4),
                                       (530_000, 128, 128, 128), (524_295, 160, 132, 4)])
