@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import torch
 
+from . import flip_bounds as FB
 from . import reference_oracle as O
 
 
@@ -72,6 +73,27 @@ def layer_sum_sparse_upstream(x, edge_index, edge_attr, w_fused, w_edge, w_out, 
     r = layer_sparse_upstream(O.layer_sum, x, edge_index, edge_attr, [w_fused, w_edge, w_out], rows, gy_rows)
     r["gw_fused"], r["gw_edge"], r["gw_out"] = r["gw"]
     return r
+
+
+def layer_sum_sparse_upstream_with_flip_bounds(x, edge_index, edge_attr, w_nodes, w_edge, w_out, rows, gy_rows, delta):
+    """layer_sum_sparse_upstream for results whose relu decisions may differ from the float64 ones (bfloat16
+    storage; float32 at scale): the same subgraph evaluated by flip_bounds.LayerTrace, which returns next to
+    every gradient how much of it hangs on relus that are zero to within `delta` of their summands' rounding.
+    For MPNNLayerCat pass flip_bounds.cat_to_sum_weights(linear.weight, F) and map the gradient back with
+    flip_bounds.cat_grad_from_sum.
+
+    Returns {"nodes", "y_rows", "num_edges", "open" (undecided message relus), and "gx", "gw_nodes", "gw_edge",
+    "gw_out" as (gradient, bound, var) triples for flip_bounds.report}.  float64, CPU."""
+    n = x.size(0)
+    eids = edges_touching(edge_index, rows, 1, n)
+    nodes, ei_sub = compact(edge_index[:, eids], rows)
+    t = FB.LayerTrace(x[nodes], ei_sub, edge_attr[eids], w_nodes, w_edge, w_out, delta)
+    at = torch.searchsorted(nodes, rows).cpu()
+    gy = torch.zeros(nodes.numel(), gy_rows.size(1), dtype=torch.float64)
+    gy[at] = gy_rows.detach().double().cpu()
+    out = t.backward(gy)
+    return {"nodes": nodes, "y_rows": t.y[at], "num_edges": int(eids.numel()), "open": int(t.open_msg.sum()),
+            "gx": out["x"], "gw_nodes": out["w_nodes"], "gw_edge": out["w_edge"], "gw_out": out["w_out"]}
 
 
 def aggregate_rows(a, b, edge_attr, w_edge, edge_index, g, dst_rows, src_rows):
