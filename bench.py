@@ -45,12 +45,14 @@ WORKLOADS = {
 }
 
 
-def make_data(name, device, scale=1.0, seed=0):
+def make_data(name, device, scale=1.0, seed=0, with_features=True):
+    """with_features=False (power-law graph only): edge list without node features and edge attributes - the
+    ranks of a partitioned run draw their own share of those afterwards (synth.powerlaw_features / _edge_attr)."""
     from mpnn_amd import synth
     if name == "powerlaw":
         n = max(int(4_000_000 * scale), 1000)
         e = max(int(100_000_000 * scale), 10_000)
-        return synth.powerlaw(device, seed, n, e, 128, 4)
+        return synth.powerlaw(device, seed, n, e, 128, 4, with_features=with_features)
     if name == "flickr":
         return synth.flickr(device, seed, max(int(89_250 * scale), 100), max(int(899_756 * scale) // 2 * 2, 200))
     if name == "modelnet":
@@ -447,9 +449,12 @@ def main():
     # exchange is the gradient all-reduce (weak scaling); single large graphs are partitioned (strong scaling)
     data_parallel = world > 1 and args.workload in ("qm9", "modelnet")
     note("generating the synthetic graph")
-    d = make_data(args.workload, dev, scale=args.scale, seed=rank if data_parallel else 0)
+    # a rank of a partitioned power-law run draws only its own rows of x and its own edges' attributes (below)
+    own_share = world > 1 and args.workload == "powerlaw" and not args.first_layer
+    d = make_data(args.workload, dev, scale=args.scale, seed=rank if data_parallel else 0, with_features=not own_share)
     n_total, e_total = d["num_nodes"], d["edge_index"].size(1)
-    F_in, H, Fe = d["x"].size(1), cfg["H"], d["edge_attr"].size(1)
+    H = cfg["H"]
+    F_in, Fe = (128, 4) if own_share else (d["x"].size(1), d["edge_attr"].size(1))
     torch.manual_seed(0)
     if args.layer == "egnn":
         if world > 1 and not data_parallel:
@@ -490,8 +495,13 @@ def main():
         dist.all_reduce(hi_sig, op=dist.ReduceOp.MAX)
         if not torch.equal(lo_sig, hi_sig):
             raise SystemExit(f"rank {rank}: the ranks built different graphs or partitions ({sig.tolist()})")
-        x = pg.local_rows(d["x"]).to(dtype).clone().requires_grad_(not args.first_layer)
-        ea = pg.local_edges(d["edge_attr"]).to(dtype).clone()
+        if own_share:
+            from mpnn_amd import synth
+            x = synth.powerlaw_features(dev, 0, n_total, F_in, pg.lo, pg.hi, dtype).requires_grad_(True)
+            ea = synth.powerlaw_edge_attr(dev, 0, e_total, Fe, pg.edge_ids, dtype)
+        else:
+            x = pg.local_rows(d["x"]).to(dtype).clone().requires_grad_(not args.first_layer)
+            ea = pg.local_edges(d["edge_attr"]).to(dtype).clone()
         if args.first_layer:
             # the layer reads the dataset's features, which every rank holds: it projects all source rows itself
             # and nothing is exchanged but the weight gradients

@@ -252,6 +252,7 @@ int32_t mpnn_count_fixup(const void* G, int64_t ldG, const float* cnt_big, const
  *     beyond it the call fails with MPNN_E_CAPACITY and touches nothing;
  *   - the call itself performs no allocation, free or synchronisation; the first call on a device looks the
  *     array's address up (hipGetSymbolAddress), so make that first call outside a stream capture;
+ *   - `stream` must belong to the CURRENT device (hipGetDevice): the array used is the current device's copy;
  *   - each GPU holds one array for the whole process: calls that overlap on one GPU (different streams) race on
  *     it - order them on one stream or use mpnn_aggregate_fwd with separate slabs.  Contents are not kept
  *     between calls and nothing needs clearing (every piece writes its slab row before it is read). */

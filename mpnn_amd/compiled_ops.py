@@ -20,11 +20,20 @@ import torch
 from torch import Tensor
 
 from . import _lib, islands, layer_fn, ops
-from .graph import graph_for
+from .graph import BYTE_COUNT_MAX, default_chunk, graph_for
 
 
 def _mask_words(h: int, dtype) -> int:
     return _lib.load().mpnn_mask_words(int(h), _lib.dtype_code(dtype)) if ops.USE_MASKBITS else 0
+
+
+def _long_rows_cap(num_edges: int) -> int:
+    """Rows the table of exact counts can need for an edge list of this size, from the integer rules of the graph
+    build alone (a split row has more than `chunk` edges, an unsplit long row more than 255): the operator's output
+    shapes then depend on input SHAPES only, and Dynamo captures it without being told to capture operators with
+    data-dependent output shapes."""
+    chunk = default_chunk(num_edges)
+    return num_edges // (chunk + 1) + (num_edges // (BYTE_COUNT_MAX + 1) if chunk > BYTE_COUNT_MAX else 0) + 1
 
 
 @torch.library.custom_op("mpnn_amd::layer_fwd", mutates_args=(), device_types="cuda")
@@ -37,7 +46,17 @@ def layer_fwd(x: Tensor, edge_index: Tensor, edge_attr: Tensor, w_nodes: Tensor,
     cnt, cnt_big = cnt if cnt is not None else (None, None)
     if cnt is None:
         cnt = torch.empty((0, h), dtype=torch.uint8, device=x.device)
-    if cnt_big is None:
+    if train:
+        # a fixed-capacity table (see _long_rows_cap); the backward reads the rows the graph's records name
+        cap = _long_rows_cap(edge_index.size(1))
+        table = torch.empty((cap, h), dtype=torch.float32, device=x.device)
+        if cnt_big is not None:
+            if cnt_big.size(0) > cap:
+                raise _lib.MpnnError(f"{cnt_big.size(0)} long rows exceed the capacity {cap} derived from the edge "
+                                     "count: was the graph structure built with a non-default chunk?")
+            table[:cnt_big.size(0)] = cnt_big
+        cnt_big = table
+    else:
         cnt_big = torch.empty((0, h), dtype=torch.float32, device=x.device)
     if maskbits is None:
         maskbits = torch.empty((edge_index.size(1) if train else 0, _mask_words(h, x.dtype) if train else 0),
@@ -53,9 +72,8 @@ def _(x, edge_index, edge_attr, w_nodes, w_edge, w_out, train):
     ab = x.new_empty((n, (3 if layer_fn.fused_x(x.dtype, x.size(1), h) else 2) * h))
     aggr = x.new_empty((n, h))
     cnt = x.new_empty((n if train else 0, h), dtype=torch.uint8)
-    # exact counts of the rows longer than a byte can count: as many rows as the graph has such rows
-    long_rows = torch.library.get_ctx().new_dynamic_size() if train else 0
-    cnt_big = x.new_empty((long_rows, h), dtype=torch.float32)
+    # exact counts of the rows longer than a byte can count: a table of fixed capacity
+    cnt_big = x.new_empty((_long_rows_cap(edge_index.size(1)) if train else 0, h), dtype=torch.float32)
     maskbits = x.new_empty((edge_index.size(1) if train else 0, _mask_words(h, x.dtype) if train else 0),
                            dtype=torch.int32)
     return y, ab, aggr, cnt, cnt_big, maskbits
@@ -71,7 +89,9 @@ def layer_bwd(gy: Tensor, x: Tensor, edge_index: Tensor, edge_attr: Tensor, ab: 
     # the layout layer_fwd's path reads
     ea_t = graph.sorted_edge_attr(edge_attr, x.dtype, "dst")[0] if one_launch else graph.sorted_edge_attr(edge_attr, x.dtype)[1]
     bits = maskbits if maskbits.size(1) > 0 else None
-    counts = (cnt, cnt_big if cnt_big.size(0) > 0 else None)
+    csr = graph.by_dst if not one_launch else None
+    has_long = csr is not None and (csr.n_split + csr.n_big) > 0
+    counts = (cnt, cnt_big if has_long else None)
     grads = layer_fn.backward_impl(gy, x, ab, aggr, counts, bits, y, ea_t, w_nodes, w_edge, w_out, graph,
                                    (need_x, need_wn, need_we, need_wout))
     none = lambda like: like.new_empty((0,))
@@ -121,14 +141,24 @@ def layer(x, edge_index, edge_attr, w_nodes, w_edge, w_out) -> Tensor:
 # global_mean_pool
 # ----------------------------------------------------------------------------------------------------------------
 # The number of graphs of a batch (batch.max() + 1) is known on the device only, so the pooled output has a
-# data-dependent first dimension.  Dynamo breaks the graph at such operators unless told to capture them (PyG's
-# own global_mean_pool breaks it with a host read at the same place); capturing is what keeps the pooled models
-# (MPNN_QM9, MPNN_ModelNet) in one graph.  MPNN_AMD_KEEP_DYNAMO_CONFIG=1 leaves the setting alone.
+# data-dependent first dimension.  Dynamo breaks the graph at such operators (the model still runs: two captured
+# graphs around an eager call, as with PyG's own global_mean_pool, which reads the count back to the host at the
+# same place) unless `torch._dynamo.config.capture_dynamic_output_shape_ops` is set.  That switch is process-wide and
+# belongs to the application, so importing this package leaves it alone; capture_pooling_in_one_graph() - or
+# MPNN_AMD_DYNAMO_CAPTURE=1 in the environment - sets it for callers who want MPNN_QM9 / MPNN_ModelNet / EGNN in ONE
+# graph (torch.compile(model, fullgraph=True)).
 import os as _os
 
-if _os.environ.get("MPNN_AMD_KEEP_DYNAMO_CONFIG", "0") != "1":
+
+def capture_pooling_in_one_graph(enable: bool = True) -> None:
+    """Sets torch._dynamo.config.capture_dynamic_output_shape_ops (process-wide): the pooled models then compile
+    into a single graph."""
     import torch._dynamo.config as _dynamo_config
-    _dynamo_config.capture_dynamic_output_shape_ops = True
+    _dynamo_config.capture_dynamic_output_shape_ops = bool(enable)
+
+
+if _os.environ.get("MPNN_AMD_DYNAMO_CAPTURE", "0") == "1":
+    capture_pooling_in_one_graph()
 
 
 @torch.library.custom_op("mpnn_amd::mean_pool", mutates_args=(), device_types="cuda")

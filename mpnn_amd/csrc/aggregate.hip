@@ -822,13 +822,15 @@ int32_t mpnn_aggregate_fwd_noalloc(const void* A, int64_t ldA, const void* B, in
   if (n_parts > 0) {
     // slab layout inside the array: [n_parts][H] partial sums, then (training) [n_parts][H] partial counts,
     // each slab starting on a 256-byte boundary
-    const int64_t slab = align_up(n_parts * (int64_t)H, 64);
+    // (n_parts * H cannot overflow below: pieces beyond the array's capacity are rejected first)
+    const int64_t slab = n_parts <= kNoAllocFloats / H ? align_up(n_parts * (int64_t)H, 64) : kNoAllocFloats + 1;
     const int64_t need = slab * (cnt ? 2 : 1);
     if (need > kNoAllocFloats)
       return fail(MPNN_E_CAPACITY,
                   "mpnn_aggregate_fwd_noalloc: %lld split pieces of %d columns need %lld bytes of scratch, the built-in "
                   "array holds %lld; use mpnn_aggregate_fwd with caller-provided slabs",
-                  (long long)n_parts, H, (long long)(need * 4), (long long)MPNN_NOALLOC_SCRATCH_BYTES);
+                  (long long)n_parts, H, (long long)(n_parts <= kNoAllocFloats / H ? need * 4 : -1),
+                  (long long)MPNN_NOALLOC_SCRATCH_BYTES);
     float* base = nullptr;
     const int32_t rc = noalloc_scratch(&base);
     if (rc != MPNN_OK) return rc;

@@ -28,7 +28,7 @@ class FlatAdam:
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         n = sum(p.numel() for p in self.params)
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self.state = torch.zeros(3, dtype=torch.float32, device=dev)   # [steps taken, step size, sqrt(1 - beta2^t)]
@@ -38,8 +38,16 @@ class FlatAdam:
                 k = p.numel()
                 self.flat[off:off + k].copy_(p.reshape(-1))
                 p.data = self.flat[off:off + k].view(p.shape)
-                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                p.grad = self._flat_grad[off:off + k].view(p.shape)
                 off += k
+
+    @property
+    def flat_grad(self) -> torch.Tensor:
+        """All gradients as one float32 vector (parameter order).  Reading it first gathers whatever backward left
+        outside the buffer (zero_grad's default drops the views), so clipping or reducing ``opt.flat_grad`` between
+        backward() and step() always sees the current gradients."""
+        self.gather_stray_gradients()
+        return self._flat_grad
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """Default: drops the gradients, so that backward hands its freshly written tensors over instead of adding
@@ -52,9 +60,9 @@ class FlatAdam:
         off = 0
         for p in self.params:
             k = p.numel()
-            p.grad = self.flat_grad[off:off + k].view(p.shape)
+            p.grad = self._flat_grad[off:off + k].view(p.shape)
             off += k
-        self.flat_grad.zero_()
+        self._flat_grad.zero_()
 
     def gather_stray_gradients(self) -> None:
         """Makes ``flat_grad`` hold every gradient and every ``.grad`` a view of it: gradients that live elsewhere
@@ -64,11 +72,11 @@ class FlatAdam:
         slots, strays = [], []
         for p in self.params:
             k = p.numel()
-            slot = self.flat_grad[off:off + k].view(p.shape)
+            slot = self._flat_grad[off:off + k].view(p.shape)
             if p.grad is None:
                 slot.zero_()
                 p.grad = slot
-            elif p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * off:
+            elif p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
                 slots.append(slot)
                 strays.append(p.grad.detach())
                 p.grad = slot
@@ -79,7 +87,7 @@ class FlatAdam:
     def step(self) -> None:
         self.gather_stray_gradients()
         lib = _lib.load()
-        _lib.check(lib.mpnn_adam_step(_lib.ptr(self.flat), _lib.ptr(self.flat_grad), _lib.ptr(self.exp_avg),
+        _lib.check(lib.mpnn_adam_step(_lib.ptr(self.flat), _lib.ptr(self._flat_grad), _lib.ptr(self.exp_avg),
                                       _lib.ptr(self.exp_avg_sq), self.flat.numel(), _lib.ptr(self.state), self.lr,
                                       self.betas[0], self.betas[1], self.eps, _lib.stream_handle(self.flat.device)),
                    "mpnn_adam_step")

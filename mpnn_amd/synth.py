@@ -129,6 +129,49 @@ def powerlaw(device="cpu", seed=0, num_nodes=4_000_000, num_edges=100_000_000, n
     src = torch.randint(0, num_nodes, (num_edges,), generator=g, device=device)
     out = {"edge_index": torch.stack([src, dst]), "num_nodes": num_nodes}
     if with_features:
-        out["x"] = torch.randn(num_nodes, num_features, generator=g, device=device).to(feature_dtype)
-        out["edge_attr"] = torch.rand(num_edges, edge_features, generator=g, device=device).to(feature_dtype)
+        out["x"] = powerlaw_features(device, seed, num_nodes, num_features, dtype=feature_dtype)
+        out["edge_attr"] = powerlaw_edge_attr(device, seed, num_edges, edge_features, dtype=feature_dtype)
+    return out
+
+
+# Node features and edge attributes of the power-law graph are drawn in blocks of 2^20 rows, every block from a
+# generator of its own (seeded by the data seed and the block number): a rank of a partitioned run can then draw
+# exactly its rows of x and its edges' attributes - the values a single GPU draws for them - without ever holding
+# the other ranks' share.
+_BLOCK = 1 << 20
+
+
+def _block(device, seed, kind, block, rows, width):
+    g = torch.Generator(device=device)
+    g.manual_seed(((seed * 2 + kind) << 32) + block + 1)
+    draw = torch.randn if kind == 0 else torch.rand
+    return draw(rows, width, generator=g, device=device)
+
+
+def powerlaw_features(device, seed, num_nodes, num_features=128, lo=0, hi=None, dtype=torch.float32):
+    """Rows lo .. hi - 1 of the power-law graph's node features (standard normal)."""
+    hi = num_nodes if hi is None else hi
+    out = torch.empty((hi - lo, num_features), dtype=dtype, device=device)
+    for b in range(lo // _BLOCK, (max(hi, lo + 1) - 1) // _BLOCK + 1 if hi > lo else 0):
+        b0 = b * _BLOCK
+        vals = _block(device, seed, 0, b, min(_BLOCK, num_nodes - b0), num_features)
+        a, z = max(lo, b0), min(hi, b0 + vals.size(0))
+        out[a - lo:z - lo] = vals[a - b0:z - b0].to(dtype)
+    return out
+
+
+def powerlaw_edge_attr(device, seed, num_edges, edge_features=4, edge_ids=None, dtype=torch.float32):
+    """Edge attributes (uniform in [0, 1)) of all edges, or of the edges ``edge_ids`` (any order) - drawn block by
+    block, so that only the requested rows are ever kept."""
+    count = num_edges if edge_ids is None else edge_ids.numel()
+    out = torch.empty((count, edge_features), dtype=dtype, device=device)
+    for b in range((num_edges + _BLOCK - 1) // _BLOCK):
+        b0 = b * _BLOCK
+        rows = min(_BLOCK, num_edges - b0)
+        if edge_ids is None:
+            out[b0:b0 + rows] = _block(device, seed, 1, b, rows, edge_features).to(dtype)
+            continue
+        mine = torch.nonzero((edge_ids >= b0) & (edge_ids < b0 + rows)).squeeze(1)
+        if mine.numel():
+            out[mine] = _block(device, seed, 1, b, rows, edge_features)[edge_ids[mine] - b0].to(dtype)
     return out

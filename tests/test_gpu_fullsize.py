@@ -118,10 +118,26 @@ def test_torch_compile_traces_the_model_without_graph_breaks(kind, mode):
         return out.detach().clone(), [p.grad.clone() for p in model.parameters()]
 
     want = run(model)
-    report = torch._dynamo.explain(model)(*args)
-    assert report.graph_break_count == 0 and report.graph_count == 1, report
-    compiled = torch.compile(model, fullgraph=True)
-    got = run(compiled)
+    import torch._dynamo.config as dynamo_config
+    assert dynamo_config.capture_dynamic_output_shape_ops is False      # importing the package changed nothing
+    if kind == "pooled model":
+        # the pooled output has one row per graph, a number only the device knows: by default Dynamo breaks the
+        # graph there (and the model still gives the eager bits) ...
+        broken = torch.compile(model)
+        assert torch.equal(run(broken)[0], want[0])
+        report = torch._dynamo.explain(model)(*args)
+        assert report.graph_break_count >= 1, report
+        torch._dynamo.reset()
+        # ... and captures it in one graph when the application says so
+        from mpnn_amd.compiled_ops import capture_pooling_in_one_graph
+        capture_pooling_in_one_graph()
+    try:
+        report = torch._dynamo.explain(model)(*args)
+        assert report.graph_break_count == 0 and report.graph_count == 1, report
+        compiled = torch.compile(model, fullgraph=True)
+        got = run(compiled)
+    finally:
+        dynamo_config.capture_dynamic_output_shape_ops = False
     assert torch.equal(got[0], want[0])
     # the head and the loss around the operators are compiled by inductor, whose reductions (e.g. the bias gradient,
     # a sum over all rows) add in another order than eager's: gradients agree to rounding, not bit for bit

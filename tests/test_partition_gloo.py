@@ -236,3 +236,29 @@ def test_partitioned_model_on_the_gpu_equals_whole_graph(world, mode, halo_mode,
     for k, v in params.items():
         for p in parts:
             assert_close(p["grads"][k], v.grad, rtol, atol_scale=10, what=k)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_starts_it():
+    """`python bench.py --gpus 2 ...` as a fresh child process - the command form of the multi-GPU scaling run (the
+    script starts its own ranks through torch.distributed.run) - rehearsed over gloo with both ranks on one GPU
+    at 1/20 scale: one JSON line from rank 0 with the rank count, the exchange volume and a positive rate."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
+                        "--scale", "0.05", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["value"] > 0 and rec["scaling"] == "strong"
+    assert rec["metric"] == "edges_per_sec_mpnn_layer_fwd_bwd" and rec["unit"] == "edges/s"
+    assert rec["exchange_per_layer_rank0"]["fwd_bytes_received"] > 0
+    assert "2 ranks" in rec["config"]["parallelism"] or "2" in rec["config"]["parallelism"]

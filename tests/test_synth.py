@@ -55,3 +55,17 @@ def test_powerlaw_shape():
     assert 3500 < int(deg.max()) < 6500                                    # expected maximum 5000
     assert float(deg.float().median()) < 25 < float(deg.float().mean()) + 1  # heavy tail: median below the mean
     assert d["x"].shape == (20000, 8) and d["edge_attr"].shape == (500000, 4)
+
+
+def test_powerlaw_shares_are_the_whole_graphs_values(monkeypatch):
+    """A rank of a partitioned run draws only its rows of x and its edges' attributes: the same values the whole
+    graph holds there, whatever the block boundaries."""
+    import torch
+    for block in (1 << 20, 1000):
+        monkeypatch.setattr(synth, "_BLOCK", block)
+        d = synth.powerlaw("cpu", 3, 5000, 30000, 16, 4)
+        assert torch.equal(d["x"][1200:3400], synth.powerlaw_features("cpu", 3, 5000, 16, 1200, 3400))
+        ids = torch.randperm(30000, generator=torch.Generator().manual_seed(1))[:7000]
+        assert torch.equal(d["edge_attr"][ids], synth.powerlaw_edge_attr("cpu", 3, 30000, 4, ids))
+    assert synth.powerlaw_features("cpu", 3, 5000, 16, 100, 100).shape == (0, 16)
+    assert "x" not in synth.powerlaw("cpu", 3, 500, 3000, 16, 4, with_features=False)

@@ -102,6 +102,14 @@ def test_flat_adam_follows_torch_adam():
     # the parameters are views of the flat buffer, and so are their gradients
     assert all(p.data_ptr() >= oa.flat.data_ptr() for p in a.parameters())
     assert all(p.grad.data_ptr() >= oa.flat_grad.data_ptr() for p in a.parameters())
+    # between backward() and step() - after the default zero_grad, which drops the views - reading flat_grad gathers
+    # the gradients first: clipping or reducing the vector sees the current values
+    oa.zero_grad()
+    F.cross_entropy(a(x, ei, ea), y).backward()
+    assert any(p.grad.data_ptr() < oa.flat.data_ptr() or p.grad.data_ptr() >= oa.flat.data_ptr() for p in a.parameters())
+    want = torch.cat([p.grad.reshape(-1) for p in a.parameters()]).clone()
+    assert torch.equal(oa.flat_grad, want)
+    assert all(p.grad.data_ptr() >= oa.flat_grad.data_ptr() for p in a.parameters())
 
 
 def _flickr_like(n=3000, e=20000, f=50):

@@ -1,3 +1,3 @@
 set -o pipefail
-timeout -k 10 900 python -u -m pytest tests/test_gpu_headline.py tests/test_gpu_egnn.py -m gpu -x -q -s --timeout 400 --timeout-method thread > gpurun_out/t3_tests.log 2>&1 || { tail -40 gpurun_out/t3_tests.log; exit 1; }
-grep -E "checked|passed|through_flips" gpurun_out/t3_tests.log | cut -c1-400
+timeout -k 10 700 python -u -m pytest tests/test_partition_gloo.py tests/test_train.py tests/test_gpu_fullsize.py -m gpu -x -q --timeout 600 --timeout-method thread > gpurun_out/t4_tests.log 2>&1 || { tail -60 gpurun_out/t4_tests.log; exit 1; }
+tail -3 gpurun_out/t4_tests.log
