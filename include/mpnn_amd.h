@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 14
+#define MPNN_ABI_VERSION 15
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -416,6 +416,22 @@ int32_t mpnn_gemm_tn_bf16(const void* G, int64_t ldg, const void* mask, int64_t 
                           int64_t ldx, const void* X2, int64_t ldx2, void* dW, int64_t lddw, float* scratch,
                           void* Gout, int64_t ldgo, int64_t N, int32_t M, int32_t K, int32_t K2,
                           mpnn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Rows exchanged between the ranks of a partitioned layer (no counterpart in the reference, which runs on one
+ * device; the exchange stands in for PyG's gathers at models/layers.py:38,110 when source rows live on other ranks).
+ *
+ * mpnn_halo_pack:    send[i, :] = table[index[i], :]   (rows this rank serves, in the order of the peers' lists),
+ *                    converted between float32 and bfloat16 on the way when the dtypes differ (the wire format).
+ * mpnn_halo_unpack:  out[r, :] = sum over k in [rowptr[r], rowptr[r+1]) of recv[pos[k], :]: the contributions
+ *                    received for this rank's rows, added in list order (float32 sums, no atomics: one fixed
+ *                    order); rows without contributions are written as zeros.  recv rows are H wide, contiguous.
+ * ------------------------------------------------------------------------- */
+int32_t mpnn_halo_pack(const void* table, int64_t ldt, int32_t table_dtype, const int32_t* index, void* send,
+                       int32_t send_dtype, int64_t rows, int32_t H, mpnn_stream_t stream);
+int32_t mpnn_halo_unpack(const void* recv, int32_t recv_dtype, const int32_t* rowptr, const int32_t* pos,
+                         void* out, int64_t ldo, int32_t out_dtype, int64_t rows, int32_t H,
+                         mpnn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Segment mean over an index list: out[g, :] = (1/max(cnt_g,1)) * sum_{p in seg g} x[col[p], :]

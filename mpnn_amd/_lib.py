@@ -14,7 +14,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 MPNN_F32 = 0
 MPNN_BF16 = 1
 MPNN_U8 = 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -131,6 +131,9 @@ SIGNATURES = {
     "mpnn_gemm_tn_bf16": (c_int32, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                     c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int32, c_int32, c_int32,
                                     c_void_p]),
+    "mpnn_halo_pack": (c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p]),
+    "mpnn_halo_unpack": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int64, c_int32,
+                                   c_void_p]),
     "mpnn_segment_mean_fwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                         c_int32, c_int32, c_void_p]),
     "mpnn_segment_mean_bwd": (c_int32, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,

@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import dense, ops
+from . import _lib
 from .dense import gemm_nt, gemm_nt_bf16, gemm_tn, gemm_tn_bf16
 from .graph import make_graph
 from .layers import MPNNLayerCat, MPNNLayerSum
@@ -225,6 +226,15 @@ class Halo:
         for c in self.serve_counts:
             off.append(off[-1] + c)
         self.serve_off = off
+        # for the library's pack / unpack kernels (GPU): the served rows as int32, and for every local row the
+        # positions of its contributions in the received buffer, ordered by sender rank (a stable sort keeps the
+        # buffer order, which is rank order): each row's sum then has one fixed order without atomics
+        self.serve_idx32 = self.serve_idx.to(torch.int32)
+        order = torch.sort(self.serve_idx, stable=True).indices
+        self.unpack_pos = order.to(torch.int32)
+        count = torch.bincount(self.serve_idx, minlength=self.n_local)
+        self.unpack_rowptr = torch.zeros(self.n_local + 1, dtype=torch.int32, device=dev)
+        self.unpack_rowptr[1:] = torch.cumsum(count, 0).to(torch.int32)
 
     # -------------------------------------------------------------------------------------------- volumes
     def wire_bytes(self, h: int, elem_bytes: int) -> dict:
@@ -255,7 +265,7 @@ class Halo:
             else:
                 work = dist.all_gather_into_tensor(out, send, group=self.group, async_op=True)
             return _Pending(work, lambda: out if wire == dtype else out.to(dtype), keep=(send,))
-        send = b_local.index_select(0, self.serve_idx).to(wire)
+        send = self._pack(b_local, wire)
         recv = b_local.new_empty((sum(self.need_counts), h), dtype=wire)
         work = _all_to_all(recv, send, self.need_counts, self.serve_counts, self.group)
         return _Pending(work, lambda: recv if wire == dtype else recv.to(dtype), keep=(send,))
@@ -281,8 +291,15 @@ class Halo:
         work = _all_to_all(recv, send, self.serve_counts, self.need_counts, self.group)
 
         def finish():
-            # every peer's list names each row at most once, so one index_add_ never adds twice into a row, and
-            # the peers are added in rank order: the sum has one fixed order
+            if recv.is_cuda:   # mpnn_halo_unpack: per row, the contributions in sender-rank order, float32 sums
+                out = g_table.new_empty((self.n_local, h))
+                lib = _lib.load()
+                _lib.check(lib.mpnn_halo_unpack(_lib.ptr(recv), _lib.dtype_code(wire), _lib.ptr(self.unpack_rowptr),
+                                                _lib.ptr(self.unpack_pos), _lib.ptr(out), h, _lib.dtype_code(dtype),
+                                                self.n_local, h, _lib.stream_handle(recv.device)), "mpnn_halo_unpack")
+                return out
+            # host tensors (the index arithmetic rehearsed over gloo on the CPU): every peer's list names each row
+            # at most once, so one index_add_ never adds twice into a row, and the peers are added in rank order
             out = g_table.new_zeros((self.n_local, h))
             for q in range(self.world):
                 lo, hi = self.serve_off[q], self.serve_off[q + 1]
@@ -290,6 +307,18 @@ class Halo:
                     out.index_add_(0, self.serve_idx[lo:hi], recv[lo:hi].to(dtype))
             return out
         return _Pending(work, finish, keep=(send,))
+
+    def _pack(self, b_local: torch.Tensor, wire) -> torch.Tensor:
+        """The rows this rank serves, in the order of the peers' lists, in the wire format."""
+        if not b_local.is_cuda or b_local.stride(1) != 1:
+            return b_local.index_select(0, self.serve_idx).to(wire)
+        h = b_local.size(1)
+        send = b_local.new_empty((self.serve_idx32.numel(), h), dtype=wire)
+        lib = _lib.load()
+        _lib.check(lib.mpnn_halo_pack(_lib.ptr(b_local), b_local.stride(0), _lib.dtype_code(b_local.dtype),
+                                      _lib.ptr(self.serve_idx32), _lib.ptr(send), _lib.dtype_code(wire),
+                                      self.serve_idx32.numel(), h, _lib.stream_handle(b_local.device)), "mpnn_halo_pack")
+        return send
 
     def scatter_sum(self, g_table: torch.Tensor) -> torch.Tensor:
         return self.start_scatter(g_table).wait()

@@ -262,3 +262,40 @@ def test_bench_two_ranks_as_the_driver_starts_it():
     assert rec["metric"] == "edges_per_sec_mpnn_layer_fwd_bwd" and rec["unit"] == "edges/s"
     assert rec["exchange_per_layer_rank0"]["fwd_bytes_received"] > 0
     assert "2 ranks" in rec["config"]["parallelism"] or "2" in rec["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,table_dtype,wire", [(128, torch.float32, torch.float32), (64, torch.float32, torch.bfloat16),
+                                                (128, torch.bfloat16, torch.bfloat16), (20, torch.float32, torch.float32),
+                                                (12, torch.bfloat16, torch.float32)])
+def test_halo_pack_and_unpack_kernels(h, table_dtype, wire):
+    """mpnn_halo_pack / mpnn_halo_unpack against the torch statements they replace: a row gather with conversion
+    to the wire format, and per row the float32 sum of the received contributions in list order."""
+    from mpnn_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(h)
+    n, served = 5000, 12000
+    table = torch.randn(n, 2 * h, generator=g).to(table_dtype).to(dev)[:, h:]        # a strided view, like B in [A | B]
+    idx = torch.randint(0, n, (served,), generator=g).to(dev)
+    send = torch.empty((served, h), dtype=wire, device=dev)
+    _lib.check(lib.mpnn_halo_pack(_lib.ptr(table), table.stride(0), _lib.dtype_code(table_dtype), _lib.ptr(idx.to(torch.int32)),
+                                  _lib.ptr(send), _lib.dtype_code(wire), served, h, _lib.stream_handle(dev)), "pack")
+    assert torch.equal(send, table.index_select(0, idx).to(wire))
+    # unpack: contributions of 3 senders, each naming a row at most once
+    lists = [torch.randperm(n, generator=g)[:k] for k in (3000, 1, 4500)]
+    serve_idx = torch.cat(lists).to(dev)
+    recv = torch.randn(serve_idx.numel(), h, generator=g).to(wire).to(dev)
+    order = torch.sort(serve_idx, stable=True).indices.to(torch.int32)
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(serve_idx, minlength=n), 0).to(torch.int32)
+    out = torch.full((n, h + 4), 7.0, dtype=table_dtype, device=dev)
+    _lib.check(lib.mpnn_halo_unpack(_lib.ptr(recv), _lib.dtype_code(wire), _lib.ptr(rowptr), _lib.ptr(order), _lib.ptr(out),
+                                    out.stride(0), _lib.dtype_code(table_dtype), n, h, _lib.stream_handle(dev)), "unpack")
+    want = torch.zeros(n, h, dtype=torch.float32, device=dev)
+    off = 0
+    for lst in lists:                                   # sender order: the float32 sum of a row has this one order
+        want.index_add_(0, lst.to(dev), recv[off:off + lst.numel()].float())
+        off += lst.numel()
+    assert torch.equal(out[:, :h], want.to(table_dtype))
+    assert bool((out[:, h:] == 7.0).all())
