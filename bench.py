@@ -89,6 +89,12 @@ def kernel_bytes(kind, n_rows, e, h, fe, s, mask_words=0, f=0):
         return e * (4 + fe * s) + n_rows * (4 + (f + h) * s)
     if kind == "island_layer_bwd":
         return e * (4 + fe * s) + n_rows * (4 + (2 * f + 2 * h) * s)
+    # whole layers for point clouds: the forward like the island form; the backward walks both sorted views and
+    # passes the gradient of the sums (float rows) from its first launch to its second, which gathers it per edge
+    if kind == "region_layer_fwd":
+        return e * (4 + fe * s) + n_rows * (4 + (f + h) * s)
+    if kind == "region_layer_bwd":
+        return e * (8 + 2 * fe * s + 4 * h) + n_rows * (8 + (2 * f + 2 * h) * s + 4 * h)
     if kind == "aggregate_fwd":
         return e * (4 + h * s + fe * s + 4 * mask_words) + n_rows * (16 + 2 * h * s + h)
     if kind == "aggregate_bwd_src":
@@ -106,7 +112,7 @@ def island_flops(kind, n_rows, e, f, h, fe):
     32-row tiles they are padded to): forward = projection + messages + update; backward = the projection and the
     messages again, gz W_out, the two weight-gradient products, [gA | gB] Wn and the backward edge pass."""
     proj, upd, edge = 2 * n_rows * 2 * h * f, 2 * n_rows * h * (f + h), e * h * (2 * fe + 3)
-    if kind == "island_layer_fwd":
+    if kind in ("island_layer_fwd", "region_layer_fwd"):
         return proj + upd + edge
     return (proj + edge) + 2 * upd + 2 * proj + e * h * (2 * fe + 3 + 2 * fe + 2)
 
@@ -603,7 +609,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         rows = {"aggregate_fwd": n_rows_fwd, "aggregate_bwd_src": n_rows_bwd, "egnn_fwd": n_rows_fwd,
                 "egnn_bwd_dst": n_rows_fwd, "egnn_bwd_src": n_rows_bwd, "island_layer_fwd": n_rows_fwd,
-                "island_layer_bwd": n_rows_fwd}
+                "island_layer_bwd": n_rows_fwd, "region_layer_fwd": n_rows_fwd, "region_layer_bwd": n_rows_fwd}
         per_kernel = {}
         from mpnn_amd import _lib
         mask_words = _lib.load().mpnn_mask_words(H, _lib.dtype_code(dtype)) if ops.USE_MASKBITS else 0
@@ -617,14 +623,14 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["GBps"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": per_kernel[dom]["GBps"] / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_src}
-        if dom.startswith("island_layer"):
+        if dom.startswith(("island_layer", "region_layer")):
             # a batch of small graphs runs as whole-layer kernels whose tiles never leave the LDS: their bytes are a
             # few megabytes and the limit is the fp32 matrix pipe (and, at this size, launch latency)
             tf = island_flops(dom, rows[dom], e_local, F_in, H, Fe) / kavg[dom] / 1e12
             roofline = {"bound": "mfma", "kernel": dom, "achieved": tf, "peak": F32_MATRIX_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": tf / F32_MATRIX_PEAK_TFLOPS, "traffic": None,
-                        "note": "algorithmic flops of the real rows and edges; the island_layer_bwd span includes "
-                                "the 5 us reduction of the weight-gradient partials"}
+                        "note": "algorithmic flops of the real rows and edges; the backward span includes the "
+                                "reduction of the weight-gradient partials"}
         mp_time = sum(kavg.values())
         model_bytes = layer_bytes_model(n_rows_fwd, e_local, H, Fe, s)
         result = {
@@ -681,7 +687,10 @@ def main():
             result["verified"] = verify_egnn_layer(layer, keep["x"], kpos, keep["edge_index"], keep["edge_attr"], dtype)
             if not result["verified"]["ok"]:
                 failed = f"verification against the CPU oracle failed: {result['verified']['worst']}"
-        if world == 1 and keep is not None and args.layer == "mpnn" and args.dtype == "f32" and not args.no_model_step:
+        # (the node-level model fixes the edge width at 4, models/mpnn.py:72-81: workloads with other widths have no
+        # such model step)
+        if world == 1 and keep is not None and args.layer == "mpnn" and args.dtype == "f32" and not args.no_model_step \
+                and keep["edge_attr"].size(1) == 4:
             note("timing the whole-model training step")
             del x, r
             layer = None

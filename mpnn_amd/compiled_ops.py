@@ -85,9 +85,10 @@ def layer_bwd(gy: Tensor, x: Tensor, edge_index: Tensor, edge_attr: Tensor, ab: 
               need_we: bool, need_wout: bool) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
     graph = graph_for(edge_index, x.size(0))
     x = x if x.is_contiguous() and x.data_ptr() % 16 == 0 else x.clone(memory_format=torch.contiguous_format)
-    one_launch = islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), False) is not None
+    plan = islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), False)
+    one_launch = plan is not None
     # the layout layer_fwd's path reads
-    ea_t = graph.sorted_edge_attr(edge_attr, x.dtype, "dst")[0] if one_launch else graph.sorted_edge_attr(edge_attr, x.dtype)[1]
+    ea_t = islands.sorted_attr(plan, graph, edge_attr, x.dtype) if one_launch else graph.sorted_edge_attr(edge_attr, x.dtype)[1]
     bits = maskbits if maskbits.size(1) > 0 else None
     csr = graph.by_dst if not one_launch else None
     has_long = csr is not None and (csr.n_split + csr.n_big) > 0

@@ -513,62 +513,83 @@ struct EdgeWeights {
   }
 };
 
-// Walks the island's edges in CSR order: begin(r) when row r starts, edge(r, s, ev, f) for every edge into r from
-// local node s with attributes ev, end(r) when the row is complete; rows without edges get begin and end too.
-// f = fetch(s) is what the edge needs of its source's rows (read ahead of use, four edges at a time, since a wave
-// that runs alone on its SIMD has nothing else to cover an LDS round trip per edge).  The row pointers, source ids
-// and attributes pass through LDS in coalesced pieces of 32 edges, so that the walk waits for no global load.
-template <typename T, typename Fetched, typename Begin, typename Fetch, typename Edge, typename End>
+// Walks the edges of rows [n0, n0 + n) in CSR order: begin(r) when row r starts, edge(r, s, ev, f) for every edge
+// into r from node col_base + s with attributes ev, end(r) when the row is complete; rows without edges get begin
+// and end too (n >= 1).
+// f = fetch(s) is what the edge needs of its source's rows, read ahead of use: the fetches of G edges go out
+// together, one group ahead of the group being used (a wave that runs almost alone on its SIMD has nothing else
+// to cover their latency; G = 4 covers an LDS round trip, fetches from global memory want 16).  The row pointers,
+// source ids and attributes pass through LDS in coalesced pieces of ST edges, and the piece after the one being
+// walked is already on its way from global memory, in registers.
+template <typename T, typename Fetched, int ST = kStageEdges, int G = 4, typename Begin, typename Fetch, typename Edge,
+          typename End>
 __device__ __forceinline__ void walk_edges(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                           const T* __restrict__ ea, int Fe, float* stage, int n0, int n, int lane,
-                                           Begin begin, Fetch fetch, Edge edge, End end) {
+                                           const T* __restrict__ ea, int Fe, float* stage, int n0, int n, int col_base,
+                                           int lane, Begin begin, Fetch fetch, Edge edge, End end) {
+  constexpr int NV = ST * kIslandFeMax / 64;   // attribute values per lane and piece
   int* rp = reinterpret_cast<int*>(stage);
   int* ecol = rp + kTileRows + 8;
-  float* eat = reinterpret_cast<float*>(ecol + kStageEdges);
+  float* eat = reinterpret_cast<float*>(ecol + ST);
   for (int i = lane; i <= n; i += 64) rp[i] = rowptr[n0 + i];
   wave_sync();
   const int e_first = __builtin_amdgcn_readfirstlane(rp[0]), e_last = __builtin_amdgcn_readfirstlane(rp[n]);
   int r = 0;
   int row_end = __builtin_amdgcn_readfirstlane(rp[1]);
   begin(0);
-  for (int eb = e_first; eb < e_last; eb += kStageEdges) {
-    const int cnt = e_last - eb < kStageEdges ? e_last - eb : kStageEdges;
-    if (lane < cnt) ecol[lane] = col[eb + lane] - n0;
-    for (int i = lane; i < cnt * kIslandFeMax; i += 64) {   // rows of 8 floats, zeros past the real width
-      const int q = i >> 3, d = i & 7;
-      eat[i] = d < Fe ? scalar_to_f32<T>(ea[(int64_t)(eb + q) * Fe + d]) : 0.f;
+  int pc = 0;        // the next piece: source id of edge `lane`, attribute values lane + 64 k (rows of 8 floats,
+  float pv[NV];      // zeros past the real width)
+  auto request = [&](int eb) __attribute__((always_inline)) {
+    const int cnt = e_last - eb < ST ? e_last - eb : ST;   // (<= 0 past the last piece: nothing is read)
+    const int e = eb + (lane < cnt ? lane : 0);
+    pc = lane < cnt ? col[e] - col_base : 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + 64 * k, q = i >> 3, d = i & 7;
+      const bool live = q < cnt && d < Fe;
+      const float v = scalar_to_f32<T>(ea[live ? (int64_t)(eb + q) * Fe + d : 0]);
+      pv[k] = live ? v : 0.f;
     }
+  };
+  if (e_first < e_last) request(e_first);
+  for (int eb = e_first; eb < e_last; eb += ST) {
+    const int cnt = e_last - eb < ST ? e_last - eb : ST;
+    if (lane < ST) ecol[lane] = pc;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) eat[lane + 64 * k] = pv[k];
     wave_sync();
-    for (int i0 = 0; i0 < cnt; i0 += 4) {   // the LDS reads of 4 edges go out together; the edges are used in order
-      int sv[4];
-      float evv[4][kIslandFeMax];
+    if (eb + ST < e_last) request(eb + ST);
+    auto fetch_group = [&](int i0, Fetched (&f)[G], int (&sv)[G]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = i0 + q < cnt ? i0 + q : cnt - 1;
-        sv[q] = ecol[i];
-        const float4 lo = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax);
-        const float4 hi = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax + 4);
-        evv[q][0] = lo.x; evv[q][1] = lo.y; evv[q][2] = lo.z; evv[q][3] = lo.w;
-        evv[q][4] = hi.x; evv[q][5] = hi.y; evv[q][6] = hi.z; evv[q][7] = hi.w;
-      }
-      Fetched f[4];
+      for (int q = 0; q < G; ++q) sv[q] = ecol[i0 + q < cnt ? i0 + q : cnt - 1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < G; ++q) {
         sv[q] = __builtin_amdgcn_readfirstlane(sv[q]);
         f[q] = fetch(sv[q]);
       }
+    };
+    Fetched f[G], fn[G];
+    int sv[G], svn[G];
+    fetch_group(0, f, sv);
+    for (int i0 = 0; i0 < cnt; i0 += G) {
+      if (i0 + G < cnt) fetch_group(i0 + G, fn, svn);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < G; ++q) {
         if (i0 + q < cnt) {
-          while (eb + i0 + q >= row_end) {
+          const int i = i0 + q;
+          const float4 lo = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax);
+          const float4 hi = *reinterpret_cast<const float4*>(eat + i * kIslandFeMax + 4);
+          const float ev[kIslandFeMax] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          while (eb + i >= row_end) {
             end(r);
             ++r;
             row_end = __builtin_amdgcn_readfirstlane(rp[r + 1]);
             begin(r);
           }
-          edge(r, sv[q], evv[q], f[q]);
+          edge(r, sv[q], ev, f[q]);
         }
       }
+#pragma unroll
+      for (int q = 0; q < G; ++q) { f[q] = fn[q]; sv[q] = svn[q]; }
     }
     wave_sync();
   }
@@ -624,7 +645,7 @@ __device__ __forceinline__ void edges_forward(const IslandLayer& a, const EdgeWe
   float* const pos_out = a.pos_out;
   float prx = 0.f, pry = 0.f, prz = 0.f;
   walk_edges<T, SourceRow<CPL>>(
-      a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, stage, n0, n, lane,
+      a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, stage, n0, n, n0, lane,
       [&](int r) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) { av[j] = ab[r * pab + lane + 64 * j]; sum[j] = 0.f; }
@@ -893,7 +914,7 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
     const int Fe = a.Fe;
     float prx = 0.f, pry = 0.f, prz = 0.f, gpl = 0.f;
     walk_edges<T, SourceRowBwd<CPL>>(
-        a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, stage, n0, n, lane,
+        a.rowptr, a.col, static_cast<const T*>(a.ea), Fe, stage, n0, n, n0, lane,
         [&](int r) __attribute__((always_inline)) {
 #pragma unroll
           for (int j = 0; j < CPL; ++j) {
@@ -1053,6 +1074,669 @@ __global__ void __launch_bounds__(256) k_island_reduce(IslandReduce a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Regions: islands of up to kRegionMax nodes over rows of x at most 4 wide (batches of point clouds)
+// ---------------------------------------------------------------------------------------------------------------
+// A k-NN cloud (experiments/modelnet_exp.py:58) is an island of a thousand nodes - far more than one tile - but its
+// rows of x are the 3 coordinates, so the x of the WHOLE island fits the LDS many times over.  The projection rows
+// A[r] = Wn_A x[r] and B[s] = Wn_B x[s] of an edge (models/layers.py:104-105) are then cheaper to recompute per edge
+// from the island's table of x (F multiply-adds per column) than to fetch (a 256-byte row of B per edge from HBM
+// or L2), and the table serves sources anywhere in the island.  A block of 8 waves takes 4 tiles of 32 consecutive
+// rows of one island, two waves per tile: each walks the edges of 16 of the tile's rows, and in the matrix-core
+// products the pair splits the output columns.
+//
+// The edge walk: a wave is four groups of 16 lanes, each group walks one row at a time, lane l of a group owning
+// columns 4 l .. 4 l + 3 (H = 64).  What an edge needs besides the lane's weights - its attributes and its other
+// end's row of x - is the same for the 16 lanes; lane k of the group loads it for the k-th edge of the row (one
+// coalesced read of the index and attribute arrays, one read of the x table) and the group takes edge k's values
+// from lane k through the LDS crossbar (ds_bpermute), which moves registers and touches no LDS bank.
+//
+// Backward: the pass over destination tiles (k_region_bwd) recomputes the sums, then gz, gW_out, ga = gz Wa and -
+// walking the incoming edges again - gA, gWe and the A-half of gWn; it leaves ga in global memory.  The gradient of
+// B[s] is a sum over the OUTGOING edges of s, so a second pass (k_region_bwd_src) walks the source-sorted view: it
+// fetches ga[d], recomputes the edge's relu mask from the x table and collects the B-half of gWn and of gx.  The
+// weight-gradient partials of both passes share one slab per block and k_region_reduce adds them in block order.
+constexpr int kRegionMax = 2048;    // nodes of the largest island
+constexpr int kRegionF = 4;         // widest x
+constexpr int kRegionTiles = 4;     // tiles per block
+constexpr int kRegionWaves = 2 * kRegionTiles;
+constexpr int kRegionRows = kRegionTiles * kTileRows;   // rows per block
+constexpr int kRegionH = 64;        // 16 lanes x 4 columns
+
+struct RegionLayer {
+  IslandLayer l;
+  int32_t cap;      // rows of the x table: the largest island
+  int32_t groups;   // blocks per island
+  const int32_t* rowptr_t; const int32_t* col_t; const void* ea_t;   // source-sorted view
+  float* ga;        // [N, H] gradient arriving at the sums
+  float* aggr;      // [N, H] the sums: written by the forward, read by the backward (null: not kept / recomputed)
+};
+
+struct RegionBlock { int n0, rn, base; bool live; };   // island [n0, n0 + rn), the block's rows start at local row base
+
+__device__ __forceinline__ RegionBlock region_block(const int32_t* island_ptr, int groups, int cap, int b) {
+  RegionBlock r;
+  const int isl = b / groups;
+  r.n0 = island_ptr[isl];
+  r.rn = island_ptr[isl + 1] - r.n0;
+  if (r.rn > cap) r.rn = cap;   // the host checked the largest island; never index past the table
+  r.base = (b - isl * groups) * kRegionRows;
+  r.live = r.base < r.rn;
+  return r;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, float b, f32x2 c) {   // v_pk_fma_f32, b for both halves
+  return __builtin_elementwise_fma(a, (f32x2)(b), c);
+}
+
+// The lane's rows of the node weight (A and B halves) and of the edge weight: columns 4 (lane % 16) + 2 p and + 1
+// as pair p, so that a multiply-add serves two columns (v_pk_fma_f32).  FEW: attribute values taken per edge (1,
+// or 8 with zeros past the real width); FW: values taken per row of x (3 or 4).
+template <typename T, int FEW, int FW>
+struct ThinWeights {
+  f32x2 wa[2][FW], wb[2][FW], we[2][FEW];
+  __device__ __forceinline__ void load(const IslandLayer& a, int lane) {
+    const T* wn = static_cast<const T*>(a.w_nodes);
+    const T* w = static_cast<const T*>(a.w_edge);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * (lane & 15) + j;
+#pragma unroll
+      for (int f = 0; f < FW; ++f) {
+        wa[j >> 1][f][j & 1] = f < a.F ? scalar_to_f32<T>(wn[c * a.F + f]) : 0.f;
+        wb[j >> 1][f][j & 1] = f < a.F ? scalar_to_f32<T>(wn[(kRegionH + c) * a.F + f]) : 0.f;
+      }
+#pragma unroll
+      for (int d = 0; d < FEW; ++d) we[j >> 1][d][j & 1] = d < a.Fe ? scalar_to_f32<T>(w[c * a.Fe + d]) : 0.f;
+    }
+  }
+  // A[node][pair p of the lane] = Wn_A[c] . x in feature order; the terms past the real width multiply zeros
+  __device__ __forceinline__ f32x2 a_of(int p, const float (&x)[FW]) const {
+    f32x2 s = wa[p][0] * x[0];
+#pragma unroll
+    for (int f = 1; f < FW; ++f) s = fma2(wa[p][f], x[f], s);
+    return s;
+  }
+  // the message before its relu: ((A + We[c] . e) + Wn_B[c] . x_src), one chain of multiply-adds in this order
+  // wherever it is computed, so that every pass sees the same bits
+  __device__ __forceinline__ f32x2 pre(int p, f32x2 a, const float (&ev)[FEW], const float (&xsrc)[FW]) const {
+    f32x2 t = a;
+#pragma unroll
+    for (int d = 0; d < FEW; ++d) t = fma2(we[p][d], ev[d], t);
+#pragma unroll
+    for (int f = 0; f < FW; ++f) t = fma2(wb[p][f], xsrc[f], t);
+    return t;
+  }
+};
+
+// The island's rows of x as a table of 4 floats per node.
+template <typename T>
+__device__ __forceinline__ void region_table(float* xs, const IslandLayer& a, const RegionBlock& rb) {
+  const T* x = static_cast<const T*>(a.x);
+  for (int i = threadIdx.x; i < rb.rn * kRegionF; i += blockDim.x) {
+    const int r = i >> 2, f = i & 3;
+    const float v = scalar_to_f32<T>(x[(int64_t)(rb.n0 + r) * a.ldx + (f < a.F ? f : 0)]);
+    xs[i] = f < a.F ? v : 0.f;
+  }
+}
+
+__device__ __forceinline__ float group_value(float v, int byte_addr) {   // v of the lane at byte_addr / 4
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+__device__ __forceinline__ int wave_max4(int v) {   // the largest of the four groups' (group-uniform) values
+  const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  const int ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
+// Sum over the 16 lanes of a group, the same bits in each of them.
+__device__ __forceinline__ float group_sum(float v) {
+  v = dpp_add<0xB1, 0xf>(v);    // quad_perm [1, 0, 3, 2]
+  v = dpp_add<0x4E, 0xf>(v);    // quad_perm [2, 3, 0, 1]
+  v = dpp_add<0x141, 0xf>(v);   // row_half_mirror
+  return dpp_add<0x140, 0xf>(v);   // row_mirror
+}
+// Sum over the four groups (lanes l, l + 16, l + 32, l + 48), the same bits in each of them.
+__device__ __forceinline__ float across_groups(float v, int lane) {
+  v += group_value(v, 4 * (lane ^ 16));
+  return v + group_value(v, 4 * (lane ^ 32));
+}
+
+template <int FEW, int FW, bool GATHER>
+struct ThinEdges {   // four consecutive edges of a group's row
+  float x[4][FW], e[4][FEW];
+  float4 g[4];       // GATHER: the lane's columns of the gradient row of the edge's other end
+};
+
+template <int FEW>
+struct ThinPiece { int c[2]; float e[2][FEW]; };   // 32 edges of a group's row: lane l holds edges l and 16 + l
+
+// Walks the edges of rows [n0, n0 + nr), nr <= 16, of a sorted view whose other ends lie in the island that starts
+// at node col_base and has last + 1 nodes.  Group g of the wave takes rows g, g + 4, g + 8, g + 12: begin(r, ok)
+// when its row r starts (ok: the row exists), edge(x, e, live, grad) for every edge with the other end's row of x,
+// the edge's attributes, live = 1.f (0.f for the padding of a group whose row is shorter than another group's: its
+// values are finite and must not count), and with GATHER the lane's four columns of gather[other end]; end(r, ok)
+// when the row is complete.  The lanes of a group see the same arguments.  The index and attribute reads of the
+// piece after the one being walked - of the next four rows, when this is the rows' last - are in flight meanwhile.
+template <typename T, int FEW, int FW, bool GATHER, typename Begin, typename Edge, typename End>
+__device__ __forceinline__ void thin_walk(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                          const T* __restrict__ ea, int Fe, const float* xs, int n0, int nr, int col_base,
+                                          int last, int lane, const float* gather, Begin begin, Edge edge, End end) {
+  const int l = lane & 15, grp = lane >> 4;
+  const int gbase = 4 * (lane & 48);   // byte address of the group's first lane for ds_bpermute
+  const int rpv = rowptr[n0 + (lane < nr ? lane : nr)];   // lane i: where row i starts (i <= nr <= 16)
+  const int e_end = __builtin_amdgcn_readlane(rpv, nr);   // one past the wave's last edge
+  const int slots = (nr + 3) >> 2;
+  struct Rows { int e0, e1, pieces; bool ok; };
+  auto rows_of = [&](int slot) __attribute__((always_inline)) {
+    Rows w;
+    const int r = 4 * slot + grp;
+    w.ok = r < nr;
+    w.e0 = __builtin_amdgcn_ds_bpermute(4 * (w.ok ? r : nr), rpv);
+    w.e1 = __builtin_amdgcn_ds_bpermute(4 * (w.ok ? r + 1 : nr), rpv);
+    w.pieces = wave_max4((w.e1 - w.e0 + 31) >> 5);
+    return w;
+  };
+  auto request = [&](const Rows& w, int p) __attribute__((always_inline)) {
+    ThinPiece<FEW> t;
+    const int eb = w.e0 + 32 * p;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool have = eb + 16 * h + l < w.e1;
+      const int64_t e = have ? eb + 16 * h + l : e_end - 1;   // (the wave has edges, or nothing is requested)
+      t.c[h] = col[e];
+#pragma unroll
+      for (int d = 0; d < FEW; ++d) {
+        const float v = scalar_to_f32<T>(ea[e * Fe + (d < Fe ? d : 0)]);
+        t.e[h][d] = (have && d < Fe) ? v : 0.f;
+      }
+    }
+    return t;
+  };
+  Rows cur_rows = rows_of(0);
+  ThinPiece<FEW> coming{};
+  if (cur_rows.pieces > 0) coming = request(cur_rows, 0);
+  for (int slot = 0; slot < slots; ++slot) {
+    const Rows w = cur_rows;
+    Rows next_rows = w;
+    if (slot + 1 < slots) next_rows = rows_of(slot + 1);
+    const int r = 4 * slot + grp;
+    begin(r, w.ok);
+    for (int p = 0; p < w.pieces; ++p) {
+      const ThinPiece<FEW> here = coming;
+      int cnt = w.e1 - (w.e0 + 32 * p);
+      cnt = cnt < 0 ? 0 : (cnt > 32 ? 32 : cnt);
+      float sx[2][FW];
+      int sc[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int c = here.c[h] - col_base;
+        c = c < 0 ? 0 : (c > last ? last : c);
+        sc[h] = c;
+        const float4 xv = *reinterpret_cast<const float4*>(xs + 4 * c);
+        const float xa4[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+        for (int f = 0; f < FW; ++f) sx[h][f] = xa4[f];
+      }
+      if (p + 1 < w.pieces) coming = request(w, p + 1);
+      else if (slot + 1 < slots && next_rows.pieces > 0) coming = request(next_rows, 0);
+      const int kmax = wave_max4(cnt);
+      auto take = [&](int k0, ThinEdges<FEW, FW, GATHER>& t) __attribute__((always_inline)) {
+        const bool hi = k0 >= 16;   // (uniform) which of the lane's two staged edges the four come from
+        const int addr = gbase + 4 * (k0 & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int f = 0; f < FW; ++f) t.x[q][f] = group_value(hi ? sx[1][f] : sx[0][f], addr + 4 * q);
+#pragma unroll
+          for (int d = 0; d < FEW; ++d) t.e[q][d] = group_value(hi ? here.e[1][d] : here.e[0][d], addr + 4 * q);
+          if constexpr (GATHER) {
+            const int node = __builtin_amdgcn_ds_bpermute(addr + 4 * q, hi ? sc[1] : sc[0]);
+            t.g[q] = *reinterpret_cast<const float4*>(gather + (int64_t)node * kRegionH + 4 * l);
+          }
+        }
+      };
+      if constexpr (FEW == 1) {
+        ThinEdges<FEW, FW, GATHER> cur, nxt;   // the next four edges' values are on their way while these are used
+        take(0, cur);
+        for (int k0 = 0; k0 < kmax; k0 += 4) {
+          if (k0 + 4 < kmax) take(k0 + 4, nxt);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) edge(cur.x[q], cur.e[q], k0 + q < cnt ? 1.f : 0.f, cur.g[q]);
+          cur = nxt;
+        }
+      } else {   // (wide attributes: one set of edge values fits the registers)
+        for (int k0 = 0; k0 < kmax; k0 += 4) {
+          ThinEdges<FEW, FW, GATHER> cur;
+          take(k0, cur);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) edge(cur.x[q], cur.e[q], k0 + q < cnt ? 1.f : 0.f, cur.g[q]);
+        }
+      }
+    }
+    if (w.pieces == 0 && slot + 1 < slots && next_rows.pieces > 0) coming = request(next_rows, 0);
+    end(r, w.ok);
+    cur_rows = next_rows;
+  }
+}
+
+// Sums of the messages into rows [row0, row0 + nr) of the island (local ids), written to sums[r * pitch + c] for
+// r = 0 .. nr - 1.
+template <typename T, int FEW, int FW>
+__device__ __forceinline__ void region_sums(const IslandLayer& a, const ThinWeights<T, FEW, FW>& tw, const float* xs,
+                                            const RegionBlock& rb, int row0, int nr, float* sums, int pitch, int lane) {
+  f32x2 av[2], sum[2];
+  thin_walk<T, FEW, FW, false>(
+      a.rowptr, a.col, static_cast<const T*>(a.ea), a.Fe, xs, rb.n0 + row0, nr, rb.n0, rb.rn - 1, lane, nullptr,
+      [&](int r, bool ok) __attribute__((always_inline)) {
+        const float4 xr = *reinterpret_cast<const float4*>(xs + 4 * (row0 + (ok ? r : 0)));
+        const float x4[4] = {xr.x, xr.y, xr.z, xr.w};
+        float xv[FW];
+#pragma unroll
+        for (int f = 0; f < FW; ++f) xv[f] = x4[f];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { av[p] = tw.a_of(p, xv); sum[p] = (f32x2)(0.f); }
+      },
+      [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          sum[p] = fma2(__builtin_elementwise_max(tw.pre(p, av[p], ev, xv), (f32x2)(0.f)), live, sum[p]);
+      },
+      [&](int r, bool ok) __attribute__((always_inline)) {
+        if (ok) *reinterpret_cast<float4*>(sums + r * pitch + 4 * (lane & 15)) = make_float4(sum[0][0], sum[0][1], sum[1][0], sum[1][1]);
+      });
+}
+
+constexpr int kRegionWp = kRegionF + kRegionH;   // row of the update weight in LDS: [x part, zeros up to 4 | aggr part]
+__host__ __device__ inline int64_t region_lds_floats(int cap, bool backward) {
+  const int px = island_pitch(kRegionF + kRegionH), pz = island_pitch(kRegionH);
+  return kIslandHeader + (int64_t)kRegionF * cap + kRegionTiles * kTileRows * (px + (backward ? pz : 0)) +
+         kRegionH * kRegionWp;
+}
+
+// W_out [H, F + H] into LDS as float rows of 68 with the x part padded to 4 columns: the tile's rows [x | 0 | aggr]
+// and the weight rows then line up, and both operands of the update products are read 16 bytes at a time.
+template <typename T>
+__device__ __forceinline__ void region_weights(float* wl, const IslandLayer& a) {
+  const T* w = static_cast<const T*>(a.w_out);
+  const int F = a.F, K = a.F + kRegionH;
+  for (int i = threadIdx.x; i < kRegionH * kRegionWp; i += blockDim.x) {
+    const int c = i / kRegionWp, k = i - c * kRegionWp;
+    const bool pad = k >= F && k < kRegionF;
+    const float v = scalar_to_f32<T>(w[c * K + (pad ? 0 : (k < F ? k : k - (kRegionF - F)))]);
+    wl[i] = pad ? 0.f : v;
+  }
+}
+
+template <typename T, int FEW, int FW>
+__global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra) {
+  extern __shared__ __align__(16) float lds[];
+  const IslandLayer& a = ra.l;
+  constexpr int H = kRegionH;
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = w >> 1, half = w & 1;
+  const int px = island_pitch(kRegionF + H);
+  float* xs = lds + kIslandHeader;
+  float* xa = xs + kRegionF * ra.cap + tile * kTileRows * px;
+  float* wl = xs + kRegionF * ra.cap + kRegionTiles * kTileRows * px;
+  const RegionBlock rb = region_block(a.island_ptr, ra.groups, ra.cap, blockIdx.x);
+  if (!rb.live) return;   // whole block
+  region_table<T>(xs, a, rb);
+  region_weights<T>(wl, a);
+  ThinWeights<T, FEW, FW> tw;
+  tw.load(a, lane);
+  __syncthreads();
+  const int t0 = rb.base + kTileRows * tile;                 // the tile's first row (local to the island)
+  const int tn = rb.rn - t0 < kTileRows ? (rb.rn - t0 < 0 ? 0 : rb.rn - t0) : kTileRows;
+  const int r0 = 16 * half;                                  // this wave's rows of the tile
+  const int nr = tn - r0 < 16 ? (tn - r0 < 0 ? 0 : tn - r0) : 16;
+  {
+    const int r = r0 + (lane >> 2), f = lane & 3;
+    xa[r * px + f] = r < tn ? xs[4 * (t0 + r) + f] : 0.f;
+  }
+  if (nr > 0) region_sums<T, FEW, FW>(a, tw, xs, rb, t0 + r0, nr, xa + r0 * px + kRegionF, px, lane);
+  for (int i = lane; i < (16 - nr) * H; i += 64) xa[(r0 + nr + i / H) * px + kRegionF + (i & (H - 1))] = 0.f;
+  if (ra.aggr)   // kept for the backward
+    for (int i = lane; i < nr * (H / 4); i += 64) {
+      const int r = i / (H / 4), c = 4 * (i % (H / 4));
+      *reinterpret_cast<float4*>(ra.aggr + (int64_t)(rb.n0 + t0 + r0 + r) * H + c) =
+          *reinterpret_cast<const float4*>(xa + (r0 + r) * px + kRegionF + c);
+    }
+  __syncthreads();
+  if (tn == 0) return;
+  // y = relu([x | aggr] W_out^T) (models/layers.py:140): the pair splits the output columns
+  f32x16 acc[1];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
+  const int c0 = 32 * half;
+  mm_wt<float, 1, true>(acc, xa, px, kRegionWp, kRegionWp, 0, wl, kRegionWp, c0, li, lh);
+  T* y = static_cast<T*>(a.y);
+  const int64_t ldy = a.ldy;
+  const int n_first = rb.n0 + t0;
+  for_acc(acc[0], lh, [&](int row, float v) __attribute__((always_inline)) {
+    if (row < tn) y[(int64_t)(n_first + row) * ldy + c0 + li] = f32_to_scalar<T>(fmaxf(v, 0.f));
+  });
+}
+
+template <typename T, int FEW, int FW>
+__global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra) {
+  extern __shared__ __align__(16) float lds[];
+  const IslandLayer& a = ra.l;
+  constexpr int H = kRegionH;
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, l = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = w >> 1, half = w & 1;
+  const int F = a.F, px = island_pitch(kRegionF + H), pz = island_pitch(H);
+  const int tile_floats = kTileRows * (px + pz), o_gz = kTileRows * px;
+  int* nrows = reinterpret_cast<int*>(lds);
+  int* n0s = nrows + 4;
+  float* xs = lds + kIslandHeader;
+  float* tiles = xs + kRegionF * ra.cap;
+  float* xa = tiles + tile * tile_floats;
+  float* ag = xa + kRegionF;
+  float* gz = xa + o_gz;
+  float* wl = tiles + kRegionTiles * tile_floats;
+  const RegionBlock rb = region_block(a.island_ptr, ra.groups, ra.cap, blockIdx.x);
+  if (!rb.live) return;   // whole block; k_region_reduce skips its slab
+  float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
+  const int64_t o_wn = (int64_t)H * (F + H), o_we = o_wn + (int64_t)2 * H * F;
+  region_table<T>(xs, a, rb);
+  region_weights<T>(wl, a);
+  const int t0 = rb.base + kTileRows * tile;
+  const int tn = rb.rn - t0 < kTileRows ? (rb.rn - t0 < 0 ? 0 : rb.rn - t0) : kTileRows;
+  const int r0 = 16 * half;
+  const int nr = tn - r0 < 16 ? (tn - r0 < 0 ? 0 : tn - r0) : 16;
+  const int n_first = rb.n0 + t0;
+  if (half == 0 && lane == 0) { nrows[tile] = tn; n0s[tile] = n_first; }
+  {
+    // gz = gy * [y > 0] (models/layers.py:140 backwards), this wave's 16 rows of the tile
+    const T* gy = static_cast<const T*>(a.gy);
+    const T* y = static_cast<const T*>(a.y);
+    const int64_t ldy = a.ldy, ldgy = a.ldgy;
+#pragma unroll 8
+    for (int i = lane; i < 16 * H; i += 64) {
+      const int r = r0 + i / H, c = i & (H - 1);
+      const int rc = r < tn ? r : (tn > 0 ? tn - 1 : 0);
+      const int64_t node = tn > 0 ? n_first + rc : rb.n0;
+      const float yv = scalar_to_f32<T>(y[node * ldy + c]);
+      const float gv = scalar_to_f32<T>(gy[node * ldgy + c]);
+      gz[r * pz + c] = (r < tn && yv > 0.f) ? gv : 0.f;
+    }
+  }
+  ThinWeights<T, FEW, FW> tw;
+  tw.load(a, lane);
+  __syncthreads();
+  {
+    const int r = r0 + (lane >> 2), f = lane & 3;
+    xa[r * px + f] = r < tn ? xs[4 * (t0 + r) + f] : 0.f;
+  }
+  if (ra.aggr) {   // the sums the forward kept
+    for (int i = lane; i < nr * (H / 4); i += 64) {
+      const int r = i / (H / 4), c = 4 * (i % (H / 4));
+      *reinterpret_cast<float4*>(ag + (r0 + r) * px + c) =
+          *reinterpret_cast<const float4*>(ra.aggr + (int64_t)(n_first + r0 + r) * H + c);
+    }
+  } else if (nr > 0) {
+    region_sums<T, FEW, FW>(a, tw, xs, rb, t0 + r0, nr, ag + r0 * px, px, lane);
+  }
+  for (int i = lane; i < (16 - nr) * H; i += 64) ag[(r0 + nr + i / H) * px + (i & (H - 1))] = 0.f;
+  __syncthreads();
+  // gW_out = gz^T [x | aggr] over the rows of the whole block
+  {
+    const int ktiles = (F + H + 31) / 32;
+    const int tasks = (H / 32) * ktiles;
+    for (int t = w; t < tasks; t += kRegionWaves)
+      block_outer<T, false>(part, F + H, 32 * (t / ktiles), 32 * (t % ktiles), tiles, tile_floats, nrows, n0s,
+                            kRegionTiles, o_gz, pz, 0, px, F, kRegionF - F, static_cast<const T*>(a.x), a.ldx, li, lh);
+  }
+  __syncthreads();
+  // [first part of gx | ga] = gz W_out, the pair taking alternate pieces of 64 columns; both replace their
+  // operands of the product above in the tile
+  // (the weight rows in LDS have the tile's column layout: a result column is a tile column; the pad columns of
+  // the x part come out as zeros)
+  if (tn > 0) {
+    for (int col0 = 64 * half; col0 < kRegionWp; col0 += 128) {
+      f32x16 acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+      mm_w<float, 2>(acc, gz, pz, H, wl, kRegionWp, col0, kRegionWp, li, lh);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int col = col0 + 32 * t + li;
+        if (col >= kRegionWp) continue;
+        for_acc(acc[t], lh, [&](int row, float v) __attribute__((always_inline)) { xa[row * px + col] = v; });
+      }
+    }
+  }
+  __syncthreads();
+  f32x2 gwe[2][FEW], gwa[2][FW];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int d = 0; d < FEW; ++d) gwe[p][d] = (f32x2)(0.f);
+#pragma unroll
+    for (int f = 0; f < FW; ++f) gwa[p][f] = (f32x2)(0.f);
+  }
+  if (nr > 0) {
+    // ga of this wave's rows for the pass over the sources
+    for (int i = lane; i < nr * (H / 4); i += 64) {
+      const int r = i / (H / 4), c = 4 * (i % (H / 4));
+      *reinterpret_cast<float4*>(ra.ga + (int64_t)(n_first + r0 + r) * H + c) =
+          *reinterpret_cast<const float4*>(ag + (r0 + r) * px + c);
+    }
+    f32x2 av[2], gar[2], ga_sum[2];
+    float xr[FW];
+    float* const gx_part = a.gx ? a.gx_part : nullptr;
+    thin_walk<T, FEW, FW, false>(
+        a.rowptr, a.col, static_cast<const T*>(a.ea), a.Fe, xs, n_first + r0, nr, rb.n0, rb.rn - 1, lane, nullptr,
+        [&](int r, bool ok) __attribute__((always_inline)) {
+          const int rr = r0 + (ok ? r : 0);
+          const float4 x4 = *reinterpret_cast<const float4*>(xs + 4 * (t0 + rr));
+          const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+          for (int f = 0; f < FW; ++f) xr[f] = xv[f];
+          const float4 g4 = *reinterpret_cast<const float4*>(ag + rr * px + 4 * l);
+          gar[0] = f32x2{g4.x, g4.y};
+          gar[1] = f32x2{g4.z, g4.w};
+#pragma unroll
+          for (int p = 0; p < 2; ++p) { av[p] = tw.a_of(p, xr); ga_sum[p] = (f32x2)(0.f); }
+        },
+        [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&) __attribute__((always_inline)) {
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const f32x2 t = tw.pre(p, av[p], ev, xv);
+            f32x2 g;
+            g[0] = t[0] > 0.f ? gar[p][0] : 0.f;
+            g[1] = t[1] > 0.f ? gar[p][1] : 0.f;
+            ga_sum[p] = fma2(g, live, ga_sum[p]);
+#pragma unroll
+            for (int d = 0; d < FEW; ++d) gwe[p][d] = fma2(g, ev[d], gwe[p][d]);   // (padding carries zero attributes)
+          }
+        },
+        [&](int r, bool ok) __attribute__((always_inline)) {
+          // ga_sum = gradient of A[r]: its share of gWn, and of gx[r] through the A half of the node weight
+          float mine = 0.f;
+#pragma unroll
+          for (int f = 0; f < FW; ++f) {
+            f32x2 t2 = (f32x2)(0.f);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              if (ok) gwa[p][f] = fma2(ga_sum[p], xr[f], gwa[p][f]);
+              t2 = __builtin_elementwise_fma(ga_sum[p], tw.wa[p][f], t2);
+            }
+            if (gx_part) {
+              const float v = group_sum(t2[0] + t2[1]);
+              mine = l == f ? v : mine;
+            }
+          }
+          if (gx_part && ok && l < F) gx_part[(int64_t)(n_first + r0 + r) * F + l] = xa[(r0 + r) * px + l] + mine;
+        });
+  }
+  __syncthreads();
+  // the groups' shares of gWe and of the A half of gWn are added inside the wave, then go through this wave's half
+  // of the (dead) gz slab, and the block adds the waves' shares in wave order
+  {
+    float* slab = gz + r0 * pz;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * l + j;
+#pragma unroll
+      for (int d = 0; d < FEW; ++d) {
+        const float v = across_groups(gwe[j >> 1][d][j & 1], lane);
+        if (lane < 16 && d < a.Fe) slab[c * a.Fe + d] = v;
+      }
+#pragma unroll
+      for (int f = 0; f < FW; ++f) {
+        const float v = across_groups(gwa[j >> 1][f][j & 1], lane);
+        if (lane < 16 && f < F) slab[H * a.Fe + c * F + f] = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < H * (a.Fe + F); e += blockDim.x) {
+    float t = 0.f;
+    for (int w2 = 0; w2 < kRegionWaves; ++w2) t += tiles[(w2 >> 1) * tile_floats + o_gz + (w2 & 1) * 16 * pz + e];
+    if (e < H * a.Fe) part[o_we + e] = t;
+    else part[o_wn + (e - H * a.Fe)] = t;
+  }
+}
+
+// The pass over the sources: 16 rows per wave.  gB[s] = sum over the edges s -> d of ga[d] where the message was
+// positive; gWn's B half += gB[s] x[s]^T, gx[s] = (what the first pass left) + gB[s] Wn_B.
+template <typename T, int FEW, int FW>
+__global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLayer ra) {
+  extern __shared__ __align__(16) float lds[];
+  const IslandLayer& a = ra.l;
+  constexpr int H = kRegionH;
+  const int lane = threadIdx.x & 63, l = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int F = a.F;
+  float* xs = lds + kIslandHeader;
+  float* slabs = xs + kRegionF * ra.cap;   // [waves][H * 4]
+  const RegionBlock rb = region_block(a.island_ptr, ra.groups, ra.cap, blockIdx.x);
+  if (!rb.live) return;
+  float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
+  const int64_t o_wnb = (int64_t)H * (F + H) + (int64_t)H * F;
+  region_table<T>(xs, a, rb);
+  ThinWeights<T, FEW, FW> tw;
+  tw.load(a, lane);
+  __syncthreads();
+  const int s0 = rb.base + 16 * w;
+  const int nr = rb.rn - s0 < 16 ? (rb.rn - s0 < 0 ? 0 : rb.rn - s0) : 16;
+  f32x2 gwb[2][FW];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int f = 0; f < FW; ++f) gwb[p][f] = (f32x2)(0.f);
+  if (nr > 0) {
+    f32x2 gb[2];
+    float xr[FW];
+    const float* const gx_part = a.gx_part;
+    T* const gx = static_cast<T*>(a.gx);
+    const int64_t ldgx = a.ldgx;
+    thin_walk<T, FEW, FW, true>(
+        ra.rowptr_t, ra.col_t, static_cast<const T*>(ra.ea_t), a.Fe, xs, rb.n0 + s0, nr, rb.n0, rb.rn - 1, lane,
+        ra.ga + (int64_t)rb.n0 * H,
+        [&](int r, bool ok) __attribute__((always_inline)) {
+          const float4 x4 = *reinterpret_cast<const float4*>(xs + 4 * (s0 + (ok ? r : 0)));
+          const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+          for (int f = 0; f < FW; ++f) xr[f] = xv[f];
+          gb[0] = gb[1] = (f32x2)(0.f);
+        },
+        [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4& g4) __attribute__((always_inline)) {
+          const f32x2 gd[2] = {f32x2{g4.x, g4.y}, f32x2{g4.z, g4.w}};
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            // the other end is the edge's destination: A from its row of x, B from this row's - the first pass's bits
+            const f32x2 t = tw.pre(p, tw.a_of(p, xv), ev, xr);
+            f32x2 g;
+            g[0] = t[0] > 0.f ? gd[p][0] : 0.f;
+            g[1] = t[1] > 0.f ? gd[p][1] : 0.f;
+            gb[p] = fma2(g, live, gb[p]);
+          }
+        },
+        [&](int r, bool ok) __attribute__((always_inline)) {
+          float mine = 0.f;
+#pragma unroll
+          for (int f = 0; f < FW; ++f) {
+            f32x2 t2 = (f32x2)(0.f);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              if (ok) gwb[p][f] = fma2(gb[p], xr[f], gwb[p][f]);
+              t2 = __builtin_elementwise_fma(gb[p], tw.wb[p][f], t2);
+            }
+            if (gx) {
+              const float v = group_sum(t2[0] + t2[1]);
+              mine = l == f ? v : mine;
+            }
+          }
+          if (gx && ok && l < F) {
+            const int64_t node = rb.n0 + s0 + r;
+            gx[node * ldgx + l] = f32_to_scalar<T>(gx_part[node * F + l] + mine);
+          }
+        });
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int f = 0; f < FW; ++f) {
+      const float v = across_groups(gwb[j >> 1][f][j & 1], lane);
+      if (lane < 16 && f < F) slabs[w * H * kRegionF + (4 * l + j) * F + f] = v;
+    }
+  __syncthreads();
+  for (int e = threadIdx.x; e < H * F; e += blockDim.x) {
+    float t = 0.f;
+    for (int w2 = 0; w2 < kRegionWaves; ++w2) t += slabs[w2 * H * kRegionF + e];
+    part[o_wnb + e] = t;
+  }
+}
+
+// Sums the live blocks' partials in a fixed order: a thread takes one element and every sixteenth block in
+// ascending order, then the sixteen sums of an element are added in ascending order.
+struct RegionReduce {
+  const float* partial; int64_t stride; const int32_t* island_ptr; int32_t n_islands, groups, cap;
+  int32_t F, H, Fe;
+  void* g_wout; void* g_wn; void* g_we;
+};
+
+constexpr int kReduceWays = 16;
+
+template <typename T>
+__global__ void __launch_bounds__(64 * kReduceWays) k_region_reduce(RegionReduce a) {
+  __shared__ float sm[kReduceWays][64];
+  const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t n1 = (int64_t)a.H * (a.F + a.H), n2 = (int64_t)2 * a.H * a.F, n3 = (int64_t)a.H * a.Fe;
+  const int64_t total = n1 + n2 + n3;
+  const int64_t e = (int64_t)blockIdx.x * 64 + el;
+  float s = 0.f;
+  if (e < total) {
+    const int blocks = a.n_islands * a.groups;
+    const float* p = a.partial + e;
+#pragma unroll 4
+    for (int b = g; b < blocks; b += kReduceWays) {
+      const float v = p[(int64_t)b * a.stride];   // (a slab that was never written may hold anything: select)
+      s += region_block(a.island_ptr, a.groups, a.cap, b).live ? v : 0.f;
+    }
+  }
+  sm[g][el] = s;
+  __syncthreads();
+  if (g == 0 && e < total) {
+    float t = sm[0][el];
+#pragma unroll
+    for (int i = 1; i < kReduceWays; ++i) t += sm[i][el];
+    T* dst;
+    if (e < n1) dst = a.g_wout ? static_cast<T*>(a.g_wout) + e : nullptr;
+    else if (e < n1 + n2) dst = a.g_wn ? static_cast<T*>(a.g_wn) + (e - n1) : nullptr;
+    else dst = a.g_we ? static_cast<T*>(a.g_we) + (e - n1 - n2) : nullptr;
+    if (dst) *dst = f32_to_scalar<T>(t);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
 // Waves (= islands) per block.  The backward keeps the rows of x out of the tile (xg) when that is what lets four
@@ -1158,6 +1842,67 @@ bool island_vec(const mpnn_island_layer* d) {
   return d->F % 4 == 0 && al(d->w_nodes) && al(d->w_out);
 }
 
+
+// --- regions ---
+int32_t check_region(const mpnn_island_layer* d, int32_t max_nodes, bool backward, const char* who) {
+  if (!d) return fail(MPNN_E_INVALID, "%s: descriptor is null", who);
+  if (d->dtype != MPNN_F32 && d->dtype != MPNN_BF16) return fail(MPNN_E_INVALID, "%s: bad dtype %d", who, d->dtype);
+  if (d->H != 64) return fail(MPNN_E_INVALID, "%s: H must be 64, got %d", who, d->H);
+  if (d->F < 1 || d->F > kRegionF || d->Fe < 1 || d->Fe > kIslandFeMax)
+    return fail(MPNN_E_INVALID, "%s: needs 1 <= F <= %d and 1 <= Fe <= 8", who, kRegionF);
+  if (max_nodes < 1 || max_nodes > kRegionMax)
+    return fail(MPNN_E_CAPACITY, "%s: islands of up to %d nodes, the limit is %d", who, max_nodes, kRegionMax);
+  if (d->pos) return fail(MPNN_E_INVALID, "%s: the coordinate update is not part of this form", who);
+  if (d->num_nodes < 0 || d->num_nodes > INT32_MAX || d->n_islands < 0 || d->tail_units != 0 || d->rows != kTileRows)
+    return fail(MPNN_E_INVALID, "%s: bad sizes (rows must be %d, tail_units 0)", who, kTileRows);
+  if ((int64_t)d->n_islands * ((max_nodes + kRegionRows - 1) / kRegionRows) > INT32_MAX)
+    return fail(MPNN_E_CAPACITY, "%s: too many islands", who);
+  if (d->n_islands == 0) return MPNN_OK;
+  if (!d->rowptr || !d->col || !d->island_ptr || !d->x || !d->ea || !d->w_nodes || !d->w_edge || !d->w_out || !d->y)
+    return fail(MPNN_E_INVALID, "%s: null pointer argument", who);
+  if (d->ldx < d->F || d->ldy < d->H) return fail(MPNN_E_INVALID, "%s: leading dimension too small", who);
+  if (backward) {
+    if (!d->gy || !d->partial || d->ldgy < d->H) return fail(MPNN_E_INVALID, "%s: gy / partial missing", who);
+    if (d->gx && (!d->gx_part || d->ldgx < d->F)) return fail(MPNN_E_INVALID, "%s: gx needs gx_part and ldgx >= F", who);
+  }
+  return MPNN_OK;
+}
+
+RegionLayer region_args(const mpnn_island_layer* d, int32_t max_nodes) {
+  RegionLayer r{};
+  r.l = to_args(d);
+  r.cap = max_nodes;
+  r.groups = (max_nodes + kRegionRows - 1) / kRegionRows;
+  return r;
+}
+
+template <typename T, int FEW, int FW>
+void launch_region(const RegionLayer& r, int kind, int blocks, int64_t lds, hipStream_t stream) {
+  const int id = 64 + ((sizeof(T) == 2) | (FEW == 1) << 1 | (FW == 4) << 2 | kind << 3);
+  if (kind == 0) {
+    allow_lds(k_region_fwd<T, FEW, FW>, id, lds);
+    k_region_fwd<T, FEW, FW><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+  } else if (kind == 1) {
+    allow_lds(k_region_bwd<T, FEW, FW>, id, lds);
+    k_region_bwd<T, FEW, FW><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+  } else {
+    allow_lds(k_region_bwd_src<T, FEW, FW>, id, lds);
+    k_region_bwd_src<T, FEW, FW><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+  }
+}
+
+template <typename T>
+void dispatch_region_t(const RegionLayer& r, int kind, int blocks, int64_t lds, hipStream_t stream) {
+  const bool fe1 = r.l.Fe == 1, f4 = r.l.F == 4;
+  if (fe1) f4 ? launch_region<T, 1, 4>(r, kind, blocks, lds, stream) : launch_region<T, 1, 3>(r, kind, blocks, lds, stream);
+  else f4 ? launch_region<T, kIslandFeMax, 4>(r, kind, blocks, lds, stream) : launch_region<T, kIslandFeMax, 3>(r, kind, blocks, lds, stream);
+}
+
+void dispatch_region(const RegionLayer& r, int dtype, int kind, int blocks, int64_t lds, hipStream_t stream) {
+  if (dtype == MPNN_F32) dispatch_region_t<float>(r, kind, blocks, lds, stream);
+  else dispatch_region_t<bf16_t>(r, kind, blocks, lds, stream);
+}
+
 }  // namespace
 }  // namespace mpnn
 
@@ -1258,6 +2003,54 @@ int32_t mpnn_island_layer_bwd(const mpnn_island_layer* d, mpnn_stream_t stream) 
   if (d->dtype == MPNN_F32) k_island_reduce<float><<<rblocks, 256, 0, stream>>>(r);
   else k_island_reduce<bf16_t><<<rblocks, 256, 0, stream>>>(r);
   MPNN_LAUNCH_CHECK("k_island_reduce");
+  return MPNN_OK;
+}
+
+int32_t mpnn_region_layer_fits(int32_t F, int32_t H, int32_t Fe, int32_t max_nodes) {
+  return H == 64 && F >= 1 && F <= kRegionF && Fe >= 1 && Fe <= kIslandFeMax && max_nodes >= 1 && max_nodes <= kRegionMax &&
+         region_lds_floats(max_nodes, true) * 4 <= kIslandLds;
+}
+
+int64_t mpnn_region_layer_partial_floats(int32_t n_islands, int32_t max_nodes, int32_t F, int32_t H, int32_t Fe) {
+  if (!mpnn_region_layer_fits(F, H, Fe, max_nodes) || n_islands < 0) return -1;
+  return (int64_t)n_islands * ((max_nodes + kRegionRows - 1) / kRegionRows) * island_partial_floats(F, H, Fe, false);
+}
+
+int32_t mpnn_region_layer_fwd(const mpnn_island_layer* d, int32_t max_nodes, float* aggr, mpnn_stream_t stream) {
+  if (int32_t rc = check_region(d, max_nodes, false, "mpnn_region_layer_fwd")) return rc;
+  if (d->n_islands == 0) return MPNN_OK;
+  RegionLayer r = region_args(d, max_nodes);
+  r.aggr = aggr;
+  dispatch_region(r, d->dtype, 0, d->n_islands * r.groups, region_lds_floats(r.cap, false) * 4, stream);
+  MPNN_LAUNCH_CHECK("k_region_fwd");
+  return MPNN_OK;
+}
+
+int32_t mpnn_region_layer_bwd(const mpnn_island_layer* d, int32_t max_nodes, const int32_t* rowptr_t,
+                              const int32_t* col_t, const void* ea_t, const float* aggr, float* ga,
+                              mpnn_stream_t stream) {
+  if (int32_t rc = check_region(d, max_nodes, true, "mpnn_region_layer_bwd")) return rc;
+  if (d->n_islands > 0 && (!rowptr_t || !col_t || !ea_t || !ga))
+    return fail(MPNN_E_INVALID, "mpnn_region_layer_bwd: the source-sorted view and the ga scratch are required");
+  RegionLayer r = region_args(d, max_nodes);
+  r.l.partial_stride = island_partial_floats(d->F, d->H, d->Fe, false);
+  r.rowptr_t = rowptr_t; r.col_t = col_t; r.ea_t = ea_t; r.ga = ga;
+  r.aggr = const_cast<float*>(aggr);
+  const int blocks = d->n_islands * r.groups;
+  if (blocks > 0) {
+    dispatch_region(r, d->dtype, 1, blocks, region_lds_floats(r.cap, true) * 4, stream);
+    MPNN_LAUNCH_CHECK("k_region_bwd");
+    const int64_t lds = (kIslandHeader + (int64_t)kRegionF * r.cap + (int64_t)kRegionWaves * d->H * kRegionF) * 4;
+    dispatch_region(r, d->dtype, 2, blocks, lds, stream);
+    MPNN_LAUNCH_CHECK("k_region_bwd_src");
+  }
+  RegionReduce rr{d->partial, r.l.partial_stride, d->island_ptr, d->n_islands, r.groups, r.cap, d->F, d->H, d->Fe,
+                  d->g_wout, d->g_wn, d->g_we};
+  const int64_t total = (int64_t)d->H * (d->F + d->H) + (int64_t)2 * d->H * d->F + (int64_t)d->H * d->Fe;
+  const int rblocks = (int)((total + 63) / 64);
+  if (d->dtype == MPNN_F32) k_region_reduce<float><<<rblocks, 64 * kReduceWays, 0, stream>>>(rr);
+  else k_region_reduce<bf16_t><<<rblocks, 64 * kReduceWays, 0, stream>>>(rr);
+  MPNN_LAUNCH_CHECK("k_region_reduce");
   return MPNN_OK;
 }
 

@@ -31,7 +31,8 @@ ITEM_ORDER_MIN_EDGES = 1 << 22
 # the build, its result read back with the item counts); see Islands.  MPNN_AMD_ISLANDS=0 switches the search and
 # with it the one-launch layers off.
 ISLAND_SEARCH_MAX_NODES = 1 << 18
-ISLAND_GIVE_UP_NODES = 33        # one more than the largest island the one-launch layers take
+ISLAND_GIVE_UP_NODES = 33        # one more than the largest island the one-wavefront layers take
+ISLAND_SEARCH_GIVE_UP = 2049     # one more than the largest island any one-launch layer takes (islands.REGION_MAX_NODES)
 # An edge list with at most this many edges per node on average is taken for a batch of small graphs: its structure
 # is built in two steps (destination view + island search first, the rest only if a general kernel asks for it).
 SMALL_GRAPHS_MAX_DEGREE = 8
@@ -315,10 +316,10 @@ class MPGraph:
         ptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         meta = torch.empty(6, dtype=torch.int32, device=dev)    # the call clears the 4 entries it owns
         ws = torch.empty(lib.mpnn_islands_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        # a row that alone spans more nodes than the island kernels take ends the search at once (point clouds,
-        # citation graphs: the common case among the graphs that have no small islands)
+        # a row that alone spans more nodes than any one-launch layer takes ends the search at once (citation
+        # graphs: the common case among the graphs that have no small islands)
         _lib.check(lib.mpnn_islands_build(_lib.ptr(csr.rowptr), _lib.ptr(csr.col), n,
-                                          ISLAND_GIVE_UP_NODES, _lib.ptr(ptr), _lib.ptr(meta), _lib.ptr(ws), ws.numel(),
+                                          ISLAND_SEARCH_GIVE_UP, _lib.ptr(ptr), _lib.ptr(meta), _lib.ptr(ws), ws.numel(),
                                           _lib.stream_handle(dev)), "mpnn_islands_build")
         return ptr, meta
 

@@ -1,10 +1,14 @@
-"""One-launch layers for batches of small graphs (the library's island kernels).
+"""One-launch layers for batches of small graphs and of point clouds (the library's island and region kernels).
 
 A mini-batch of molecules (data/dataset.py:94-96) is a disjoint union of graphs of a few dozen nodes, and a layer
 (models/layers.py:91-140) never moves data between them.  When the graph structure knows its islands (graph.Islands)
 and they are small enough, the layer runs as mpnn_island_layer_fwd / mpnn_island_layer_bwd: one wavefront per
 island, every intermediate in LDS, one launch forward and two backward, instead of the general sequence of GEMM and
 edge-pass launches whose working sets would be a few kilobytes each.
+
+Islands of up to 2048 nodes over rows of x at most 4 wide (the k-NN clouds of experiments/modelnet_exp.py:58 with
+``data.pos`` as x) take the REGION form of the same idea, mpnn_region_layer_fwd / _bwd: the x of a whole island sits
+in LDS and the projection of an edge's two ends is recomputed from it instead of fetched.
 """
 from __future__ import annotations
 
@@ -21,13 +25,17 @@ ROWS = 32              # height of a tile (one matrix-core tile): the largest is
 # Beyond this many islands the general path wins (measured on QM9-shaped batches: 1024 molecules 0.123 vs 0.160 ms
 # per layer step, 2048 molecules 0.229 vs 0.213 ms): its GEMMs use the bfloat16 matrix cores at 2.7 times the rate.
 COUNT_MAX = int(os.environ.get("MPNN_AMD_ISLANDS_MAX", "1536"))
+REGIONS_ENABLED = os.environ.get("MPNN_AMD_REGIONS", "1") != "0"
+REGION_ROWS = 128      # rows of one block of the region kernels
+REGION_MAX_NODES = 2048
 
 
 class Plan:
-    __slots__ = ("rows", "tail_units", "egnn")
+    __slots__ = ("rows", "tail_units", "egnn", "region_nodes")
 
-    def __init__(self, rows, tail_units, egnn):
+    def __init__(self, rows, tail_units, egnn, region_nodes=0):
         self.rows, self.tail_units, self.egnn = rows, tail_units, egnn
+        self.region_nodes = region_nodes      # > 0: the region form, with this bound on the largest island
 
 
 def plan_for(graph: MPGraph, f: int, h: int, fe: int, egnn: bool) -> Plan | None:
@@ -36,21 +44,37 @@ def plan_for(graph: MPGraph, f: int, h: int, fe: int, egnn: bool) -> Plan | None
     isl = getattr(graph, "islands", None)
     if isl is None:
         return None
-    key = (f, h, fe, egnn, COUNT_MAX)
+    key = (f, h, fe, egnn, COUNT_MAX, REGIONS_ENABLED)
     plans = graph._scratch.setdefault("island_plans", {})    # per graph: the answer depends on the shapes only
     if key not in plans:
-        plans[key] = _plan(isl, f, h, fe, egnn)
+        plans[key] = _plan(isl, f, h, fe, egnn, graph.num_dst)
     return plans[key]
 
 
-def _plan(isl, f: int, h: int, fe: int, egnn: bool) -> Plan | None:
-    if isl.count == 0 or isl.count > COUNT_MAX or isl.max_nodes > ROWS:
+def _plan(isl, f: int, h: int, fe: int, egnn: bool, num_nodes: int) -> Plan | None:
+    if isl.count == 0:
+        return None
+    if isl.max_nodes > ROWS:
+        return _region_plan(isl, f, h, fe, egnn, num_nodes)
+    if isl.count > COUNT_MAX:
         return None
     if h not in (64, 128) or not 1 <= fe <= 8 or f < 1:
         return None
     if _lib.load().mpnn_island_layer_waves(f, h, fe, int(egnn), 1) < 1:
         return None
     return Plan(ROWS, (isl.tail_rows + ROWS - 1) // ROWS, egnn)
+
+
+def _region_plan(isl, f: int, h: int, fe: int, egnn: bool, num_nodes: int) -> Plan | None:
+    if egnn or not REGIONS_ENABLED or isl.tail_rows or isl.max_nodes > REGION_MAX_NODES:
+        return None
+    if not _lib.load().mpnn_region_layer_fits(f, h, fe, isl.max_nodes):
+        return None
+    # every island takes ceil(largest / 128) blocks: not worth it when most of them would find no rows
+    groups = (isl.max_nodes + REGION_ROWS - 1) // REGION_ROWS
+    if isl.count * groups * REGION_ROWS > 8 * max(num_nodes, 1):
+        return None
+    return Plan(ROWS, 0, False, isl.max_nodes)
 
 
 def _desc(plan: Plan, graph: MPGraph, x, ea_s, w_nodes, w_edge, w_out, y, pos=None, w_pos=None) -> _lib.IslandLayerDesc:
@@ -82,9 +106,74 @@ def _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
     return x, ea_s, w_nodes.contiguous(), w_edge.contiguous(), w_out.contiguous()
 
 
-def forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, pos=None, w_pos=None):
+def sorted_attr(plan: Plan, graph: MPGraph, edge_attr, dtype):
+    """edge_attr in the layout the plan's kernels read - what forward() hands on as ``saved[1]``: destination order
+    for the island form; for the region form both orders stacked, [2, E, Fe] (destination order, source order)."""
+    if not plan.region_nodes:
+        return graph.sorted_edge_attr(edge_attr, dtype, "dst")[0]
+    ea_s, ea_t = graph.sorted_edge_attr(edge_attr, dtype)
+    hit = graph._scratch.get("region_ea")
+    if hit is None or hit[0] is not ea_s or hit[1] is not ea_t:     # (the cached pair is the same two objects)
+        hit = (ea_s, ea_t, torch.stack([ea_s, ea_t]))
+        graph._scratch["region_ea"] = hit
+    return hit[2]
+
+
+def _region_forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, keep: bool):
+    n = x.size(0)
+    x, _, w_nodes, w_edge, w_out = _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph)
+    both = sorted_attr(plan, graph, edge_attr, x.dtype)
+    lib = _lib.load()
+    y = torch.empty((n, w_out.size(0)), dtype=x.dtype, device=x.device)
+    # the sums over incoming edges, kept for the backward (which would otherwise walk the edges once more)
+    aggr = torch.empty((n, w_out.size(0)), dtype=torch.float32, device=x.device) if keep else None
+    d = _desc(plan, graph, x, both[0], w_nodes, w_edge, w_out, y)
+    with _Timed("region_layer_fwd", x.device):
+        _lib.check(lib.mpnn_region_layer_fwd(ctypes.byref(d), plan.region_nodes, _lib.ptr(aggr),
+                                             _lib.stream_handle(x.device)), "mpnn_region_layer_fwd")
+    return y, None, (x, both, w_nodes, w_edge, w_out, aggr, None)
+
+
+def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs):
+    x, both, w_nodes, w_edge, w_out = saved[:5]
+    aggr = saved[5] if len(saved) > 5 else None
+    if aggr is not None and (aggr.dtype != torch.float32 or not aggr.is_contiguous()):
+        aggr = None                                   # (recomputed)
+    ea_s, ea_t = both[0], both[1]
+    need_x, need_wn, need_we, need_wout = needs
+    lib = _lib.load()
+    dev, dt = x.device, x.dtype
+    n, f = x.shape
+    h = w_out.size(0)
+    gy = gy if gy.is_contiguous() else gy.contiguous()
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y)
+    d.gy, d.ldgy = _lib.ptr(gy), gy.stride(0)
+    gx = torch.empty((n, f), dtype=dt, device=dev) if need_x else None
+    g_wn = torch.empty_like(w_nodes) if need_wn else None
+    g_we = torch.empty_like(w_edge) if need_we else None
+    g_wout = torch.empty_like(w_out) if need_wout else None
+    d.gx, d.ldgx = _lib.ptr(gx), (gx.stride(0) if gx is not None else 0)
+    d.g_wn, d.g_we, d.g_wout = _lib.ptr(g_wn), _lib.ptr(g_we), _lib.ptr(g_wout)
+    floats = lib.mpnn_region_layer_partial_floats(graph.islands.count, plan.region_nodes, f, h, ea_s.size(1))
+    if floats < 0:
+        raise _lib.MpnnError("mpnn_region_layer_partial_floats rejected the layer's shape")
+    d.partial = _lib.ptr(graph.scratch("region_partial", (max(floats, 1),), torch.float32, dev))
+    if need_x:
+        d.gx_part = _lib.ptr(graph.scratch("region_gx", (n, f), torch.float32, dev))
+    ga = graph.scratch("region_ga", (n, h), torch.float32, dev)
+    src = graph.by_src
+    with _Timed("region_layer_bwd", dev):
+        _lib.check(lib.mpnn_region_layer_bwd(ctypes.byref(d), plan.region_nodes, _lib.ptr(src.rowptr), _lib.ptr(src.col),
+                                             _lib.ptr(ea_t), _lib.ptr(aggr), _lib.ptr(ga), _lib.stream_handle(dev)),
+                   "mpnn_region_layer_bwd")
+    return gx, g_wn, g_we, g_wout, None, None
+
+
+def forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, pos=None, w_pos=None, keep=True):
     """y (and pos' for the EGNN form) of one layer.  Returns (y, pos_out | None, saved) where ``saved`` are the
-    contiguous tensors the backward needs."""
+    contiguous tensors the backward needs (``keep`` false: no backward will follow)."""
+    if plan.region_nodes:
+        return _region_forward(plan, graph, x, edge_attr, w_nodes, w_edge, w_out, keep)
     x, ea_s, w_nodes, w_edge, w_out = _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph)
     lib = _lib.load()
     y = torch.empty((x.size(0), w_out.size(0)), dtype=x.dtype, device=x.device)
@@ -103,6 +192,8 @@ def forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, po
 def backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None):
     """Gradients of one layer.  ``needs`` = (x, w_nodes, w_edge, w_out) wanted; returns (gx, g_wn, g_we, g_wout,
     gpos, g_wpos), None where not wanted (gpos / g_wpos only for the EGNN form)."""
+    if plan.region_nodes:
+        return _region_backward(plan, graph, gy, y, saved, needs)
     x, ea_s, w_nodes, w_edge, w_out, pos, w_pos = saved
     need_x, need_wn, need_we, need_wout = needs
     lib = _lib.load()

@@ -31,7 +31,9 @@ def timeit(fn, reps=50):
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-    for k1, k2, m, relu, masked in [(3, 0, 128, False, False), (3, 64, 64, True, False), (64, 0, 67, False, False),
+    for k1, k2, m, relu, masked in [(3, 0, 128, False, False), (4, 0, 128, False, False), (3, 64, 64, True, False),
+                                    (4, 64, 64, True, False), (64, 128, 3, False, True), (64, 128, 4, False, True),
+                                    (64, 0, 67, False, False),
                                     (128, 0, 3, False, True), (64, 0, 128, False, False), (64, 64, 64, True, False),
                                     (64, 0, 128, False, True), (128, 0, 64, False, True), (11, 0, 128, False, False),
                                     (500, 0, 128, False, False)]:
@@ -45,7 +47,8 @@ def main():
         print(f"{t:7.1f} us | torch.mm(first seg) ", end="", flush=True)
         t2 = timeit(lambda: torch.mm(x1, w1.t()))
         print(f"{t2:7.1f} us", flush=True)
-    for m, k, k2, masked in [(128, 3, 0, False), (64, 3, 64, True), (128, 64, 0, False), (64, 64, 64, True), (128, 11, 0, False),
+    for m, k, k2, masked in [(128, 3, 0, False), (128, 4, 0, False), (64, 3, 64, True), (64, 4, 64, True), (128, 64, 0, False),
+                             (64, 64, 64, True), (128, 11, 0, False),
                              (128, 500, 0, False)]:
         g, x = torch.randn(n, m, device=dev), torch.randn(n, k, device=dev)
         x2 = torch.randn(n, k2, device=dev) if k2 else None
