@@ -213,8 +213,12 @@ __device__ long long* g_island_prof = nullptr;
 #define ISLAND_PROF(slot) \
   do { if (g_island_prof && (threadIdx.x & 63) == 0) \
          g_island_prof[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
+#define REGION_PROF(slot) \
+  do { if (g_island_prof && (threadIdx.x & 63) == 0) \
+         g_island_prof[((int64_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = wall_clock64(); } while (0)
 #else
 #define ISLAND_PROF(slot) do {} while (0)
+#define REGION_PROF(slot) do {} while (0)
 #endif
 
 struct Unit { int n0, n; };
@@ -1169,14 +1173,27 @@ struct ThinWeights {
   }
 };
 
-// The island's rows of x as a table of 4 floats per node.
+// The island's rows of x as a table of 4 floats per node.  (Eight loads per thread are requested before the first
+// is stored: a loop of load-then-store would pay one trip to memory per iteration.)
 template <typename T>
 __device__ __forceinline__ void region_table(float* xs, const IslandLayer& a, const RegionBlock& rb) {
   const T* x = static_cast<const T*>(a.x);
-  for (int i = threadIdx.x; i < rb.rn * kRegionF; i += blockDim.x) {
-    const int r = i >> 2, f = i & 3;
-    const float v = scalar_to_f32<T>(x[(int64_t)(rb.n0 + r) * a.ldx + (f < a.F ? f : 0)]);
-    xs[i] = f < a.F ? v : 0.f;
+  const int total = rb.rn * kRegionF;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 8 * blockDim.x) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * blockDim.x;
+      const int ic = i < total ? i : 0;
+      const int r = ic >> 2, f = ic & 3;
+      const float t = scalar_to_f32<T>(x[(int64_t)(rb.n0 + r) * a.ldx + (f < a.F ? f : 0)]);
+      v[k] = f < a.F ? t : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * blockDim.x;
+      if (i < total) xs[i] = v[k];
+    }
   }
 }
 
@@ -1357,16 +1374,31 @@ __host__ __device__ inline int64_t region_lds_floats(int cap, bool backward) {
 // W_out [H, F + H] into LDS as float rows of 68 with the x part padded to 4 columns: the tile's rows [x | 0 | aggr]
 // and the weight rows then line up, and both operands of the update products are read 16 bytes at a time.
 template <typename T>
-__device__ __forceinline__ void region_weights(float* wl, const IslandLayer& a) {
-  const T* w = static_cast<const T*>(a.w_out);
-  const int F = a.F, K = a.F + kRegionH;
-  for (int i = threadIdx.x; i < kRegionH * kRegionWp; i += blockDim.x) {
-    const int c = i / kRegionWp, k = i - c * kRegionWp;
-    const bool pad = k >= F && k < kRegionF;
-    const float v = scalar_to_f32<T>(w[c * K + (pad ? 0 : (k < F ? k : k - (kRegionF - F)))]);
-    wl[i] = pad ? 0.f : v;
+struct RegionWeights {
+  static constexpr int total = kRegionH * kRegionWp;
+  static constexpr int per = (total + 64 * kRegionWaves - 1) / (64 * kRegionWaves);
+  float v[per];
+  __device__ __forceinline__ void request(const IslandLayer& a) {   // all of a thread's loads go out together
+    const T* w = static_cast<const T*>(a.w_out);
+    const int F = a.F, K = a.F + kRegionH;
+#pragma unroll
+    for (int k = 0; k < per; ++k) {
+      const int i = threadIdx.x + k * 64 * kRegionWaves;
+      const int ic = i < total ? i : 0;
+      const int c = ic / kRegionWp, kk = ic - c * kRegionWp;
+      const bool pad = kk >= F && kk < kRegionF;
+      const float t = scalar_to_f32<T>(w[c * K + (pad ? 0 : (kk < F ? kk : kk - (kRegionF - F)))]);
+      v[k] = pad ? 0.f : t;
+    }
   }
-}
+  __device__ __forceinline__ void store(float* wl) const {
+#pragma unroll
+    for (int k = 0; k < per; ++k) {
+      const int i = threadIdx.x + k * 64 * kRegionWaves;
+      if (i < total) wl[i] = v[k];
+    }
+  }
+};
 
 template <typename T, int FEW, int FW>
 __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra) {
@@ -1382,11 +1414,16 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
   float* wl = xs + kRegionF * ra.cap + kRegionTiles * kTileRows * px;
   const RegionBlock rb = region_block(a.island_ptr, ra.groups, ra.cap, blockIdx.x);
   if (!rb.live) return;   // whole block
-  region_table<T>(xs, a, rb);
-  region_weights<T>(wl, a);
+  REGION_PROF(0);
+  // everything the block reads before its first barrier is requested before anything is waited for
   ThinWeights<T, FEW, FW> tw;
   tw.load(a, lane);
+  RegionWeights<T> wo;
+  wo.request(a);
+  region_table<T>(xs, a, rb);
+  wo.store(wl);
   __syncthreads();
+  REGION_PROF(1);
   const int t0 = rb.base + kTileRows * tile;                 // the tile's first row (local to the island)
   const int tn = rb.rn - t0 < kTileRows ? (rb.rn - t0 < 0 ? 0 : rb.rn - t0) : kTileRows;
   const int r0 = 16 * half;                                  // this wave's rows of the tile
@@ -1396,6 +1433,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
     xa[r * px + f] = r < tn ? xs[4 * (t0 + r) + f] : 0.f;
   }
   if (nr > 0) region_sums<T, FEW, FW>(a, tw, xs, rb, t0 + r0, nr, xa + r0 * px + kRegionF, px, lane);
+  REGION_PROF(2);
   for (int i = lane; i < (16 - nr) * H; i += 64) xa[(r0 + nr + i / H) * px + kRegionF + (i & (H - 1))] = 0.f;
   if (ra.aggr)   // kept for the backward
     for (int i = lane; i < nr * (H / 4); i += 64) {
@@ -1404,6 +1442,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
           *reinterpret_cast<const float4*>(xa + (r0 + r) * px + kRegionF + c);
     }
   __syncthreads();
+  REGION_PROF(3);
   if (tn == 0) return;
   // y = relu([x | aggr] W_out^T) (models/layers.py:140): the pair splits the output columns
   f32x16 acc[1];
@@ -1411,12 +1450,14 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
   for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
   const int c0 = 32 * half;
   mm_wt<float, 1, true>(acc, xa, px, kRegionWp, kRegionWp, 0, wl, kRegionWp, c0, li, lh);
+  REGION_PROF(4);
   T* y = static_cast<T*>(a.y);
   const int64_t ldy = a.ldy;
   const int n_first = rb.n0 + t0;
   for_acc(acc[0], lh, [&](int row, float v) __attribute__((always_inline)) {
     if (row < tn) y[(int64_t)(n_first + row) * ldy + c0 + li] = f32_to_scalar<T>(fmaxf(v, 0.f));
   });
+  REGION_PROF(5);
 }
 
 template <typename T, int FEW, int FW>
@@ -1441,8 +1482,11 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
   if (!rb.live) return;   // whole block; k_region_reduce skips its slab
   float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
   const int64_t o_wn = (int64_t)H * (F + H), o_we = o_wn + (int64_t)2 * H * F;
-  region_table<T>(xs, a, rb);
-  region_weights<T>(wl, a);
+  REGION_PROF(0);
+  ThinWeights<T, FEW, FW> tw;
+  tw.load(a, lane);
+  RegionWeights<T> wo;
+  wo.request(a);
   const int t0 = rb.base + kTileRows * tile;
   const int tn = rb.rn - t0 < kTileRows ? (rb.rn - t0 < 0 ? 0 : rb.rn - t0) : kTileRows;
   const int r0 = 16 * half;
@@ -1464,14 +1508,16 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
       gz[r * pz + c] = (r < tn && yv > 0.f) ? gv : 0.f;
     }
   }
-  ThinWeights<T, FEW, FW> tw;
-  tw.load(a, lane);
+  region_table<T>(xs, a, rb);
+  wo.store(wl);
   __syncthreads();
+  REGION_PROF(1);
   {
     const int r = r0 + (lane >> 2), f = lane & 3;
     xa[r * px + f] = r < tn ? xs[4 * (t0 + r) + f] : 0.f;
   }
   if (ra.aggr) {   // the sums the forward kept
+#pragma unroll 4
     for (int i = lane; i < nr * (H / 4); i += 64) {
       const int r = i / (H / 4), c = 4 * (i % (H / 4));
       *reinterpret_cast<float4*>(ag + (r0 + r) * px + c) =
@@ -1482,6 +1528,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
   }
   for (int i = lane; i < (16 - nr) * H; i += 64) ag[(r0 + nr + i / H) * px + (i & (H - 1))] = 0.f;
   __syncthreads();
+  REGION_PROF(2);
   // gW_out = gz^T [x | aggr] over the rows of the whole block
   {
     const int ktiles = (F + H + 31) / 32;
@@ -1491,6 +1538,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
                             kRegionTiles, o_gz, pz, 0, px, F, kRegionF - F, static_cast<const T*>(a.x), a.ldx, li, lh);
   }
   __syncthreads();
+  REGION_PROF(3);
   // [first part of gx | ga] = gz W_out, the pair taking alternate pieces of 64 columns; both replace their
   // operands of the product above in the tile
   // (the weight rows in LDS have the tile's column layout: a result column is a tile column; the pad columns of
@@ -1512,6 +1560,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     }
   }
   __syncthreads();
+  REGION_PROF(4);
   f32x2 gwe[2][FEW], gwa[2][FW];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
@@ -1527,6 +1576,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
       *reinterpret_cast<float4*>(ra.ga + (int64_t)(n_first + r0 + r) * H + c) =
           *reinterpret_cast<const float4*>(ag + (r0 + r) * px + c);
     }
+    REGION_PROF(5);
     f32x2 av[2], gar[2], ga_sum[2];
     float xr[FW];
     float* const gx_part = a.gx ? a.gx_part : nullptr;
@@ -1575,7 +1625,9 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
           if (gx_part && ok && l < F) gx_part[(int64_t)(n_first + r0 + r) * F + l] = xa[(r0 + r) * px + l] + mine;
         });
   }
+  REGION_PROF(6);
   __syncthreads();
+  REGION_PROF(7);
   // the groups' shares of gWe and of the A half of gWn are added inside the wave, then go through this wave's half
   // of the (dead) gz slab, and the block adds the waves' shares in wave order
   {
@@ -1602,6 +1654,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     if (e < H * a.Fe) part[o_we + e] = t;
     else part[o_wn + (e - H * a.Fe)] = t;
   }
+  REGION_PROF(8);
 }
 
 // The pass over the sources: 16 rows per wave.  gB[s] = sum over the edges s -> d of ga[d] where the message was
@@ -1620,10 +1673,12 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
   if (!rb.live) return;
   float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
   const int64_t o_wnb = (int64_t)H * (F + H) + (int64_t)H * F;
-  region_table<T>(xs, a, rb);
+  REGION_PROF(0);
   ThinWeights<T, FEW, FW> tw;
   tw.load(a, lane);
+  region_table<T>(xs, a, rb);
   __syncthreads();
+  REGION_PROF(1);
   const int s0 = rb.base + 16 * w;
   const int nr = rb.rn - s0 < 16 ? (rb.rn - s0 < 0 ? 0 : rb.rn - s0) : 16;
   f32x2 gwb[2][FW];
@@ -1680,6 +1735,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
           }
         });
   }
+  REGION_PROF(2);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1693,6 +1749,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
     for (int w2 = 0; w2 < kRegionWaves; ++w2) t += slabs[w2 * H * kRegionF + e];
     part[o_wnb + e] = t;
   }
+  REGION_PROF(3);
 }
 
 // Sums the live blocks' partials in a fixed order: a thread takes one element and every sixteenth block in
