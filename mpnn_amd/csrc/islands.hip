@@ -1161,15 +1161,20 @@ struct ThinWeights {
     for (int f = 1; f < FW; ++f) s = fma2(wa[p][f], x[f], s);
     return s;
   }
-  // the message before its relu: ((A + We[c] . e) + Wn_B[c] . x_src), one chain of multiply-adds in this order
-  // wherever it is computed, so that every pass sees the same bits
-  __device__ __forceinline__ f32x2 pre(int p, f32x2 a, const float (&ev)[FEW], const float (&xsrc)[FW]) const {
-    f32x2 t = a;
+  __device__ __forceinline__ f32x2 b_of(int p, const float (&x)[FW]) const {   // B[node], likewise
+    f32x2 s = wb[p][0] * x[0];
 #pragma unroll
-    for (int d = 0; d < FEW; ++d) t = fma2(we[p][d], ev[d], t);
+    for (int f = 1; f < FW; ++f) s = fma2(wb[p][f], x[f], s);
+    return s;
+  }
+  // the message before its relu, associated as the reference does: (A[dst] + B[src]) + We . e
+  // (models/layers.py:128), the edge term a chain of multiply-adds in feature order - the same operations in the
+  // same order wherever it is computed, so that every pass sees the same bits
+  __device__ __forceinline__ f32x2 pre(int p, f32x2 a, f32x2 b, const float (&ev)[FEW]) const {
+    f32x2 es = we[p][0] * ev[0];
 #pragma unroll
-    for (int f = 0; f < FW; ++f) t = fma2(wb[p][f], xsrc[f], t);
-    return t;
+    for (int d = 1; d < FEW; ++d) es = fma2(we[p][d], ev[d], es);
+    return (a + b) + es;
   }
 };
 
@@ -1357,7 +1362,7 @@ __device__ __forceinline__ void region_sums(const IslandLayer& a, const ThinWeig
       [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-          sum[p] = fma2(__builtin_elementwise_max(tw.pre(p, av[p], ev, xv), (f32x2)(0.f)), live, sum[p]);
+          sum[p] = fma2(__builtin_elementwise_max(tw.pre(p, av[p], tw.b_of(p, xv), ev), (f32x2)(0.f)), live, sum[p]);
       },
       [&](int r, bool ok) __attribute__((always_inline)) {
         if (ok) *reinterpret_cast<float4*>(sums + r * pitch + 4 * (lane & 15)) = make_float4(sum[0][0], sum[0][1], sum[1][0], sum[1][1]);
@@ -1597,7 +1602,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
         [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&) __attribute__((always_inline)) {
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
-            const f32x2 t = tw.pre(p, av[p], ev, xv);
+            const f32x2 t = tw.pre(p, av[p], tw.b_of(p, xv), ev);
             f32x2 g;
             g[0] = t[0] > 0.f ? gar[p][0] : 0.f;
             g[1] = t[1] > 0.f ? gar[p][1] : 0.f;
@@ -1687,7 +1692,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
 #pragma unroll
     for (int f = 0; f < FW; ++f) gwb[p][f] = (f32x2)(0.f);
   if (nr > 0) {
-    f32x2 gb[2];
+    f32x2 gb[2], bv[2];
     float xr[FW];
     const float* const gx_part = a.gx_part;
     T* const gx = static_cast<T*>(a.gx);
@@ -1700,14 +1705,15 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
           const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
           for (int f = 0; f < FW; ++f) xr[f] = xv[f];
-          gb[0] = gb[1] = (f32x2)(0.f);
+#pragma unroll
+          for (int p = 0; p < 2; ++p) { bv[p] = tw.b_of(p, xr); gb[p] = (f32x2)(0.f); }
         },
         [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4& g4) __attribute__((always_inline)) {
           const f32x2 gd[2] = {f32x2{g4.x, g4.y}, f32x2{g4.z, g4.w}};
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             // the other end is the edge's destination: A from its row of x, B from this row's - the first pass's bits
-            const f32x2 t = tw.pre(p, tw.a_of(p, xv), ev, xr);
+            const f32x2 t = tw.pre(p, tw.a_of(p, xv), bv[p], ev);
             f32x2 g;
             g[0] = t[0] > 0.f ? gd[p][0] : 0.f;
             g[1] = t[1] > 0.f ? gd[p][1] : 0.f;

@@ -107,39 +107,33 @@ def _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
 
 
 def sorted_attr(plan: Plan, graph: MPGraph, edge_attr, dtype):
-    """edge_attr in the layout the plan's kernels read - what forward() hands on as ``saved[1]``: destination order
-    for the island form; for the region form both orders stacked, [2, E, Fe] (destination order, source order)."""
+    """edge_attr in the layout(s) the plan's kernels read: destination order for the island form (what forward()
+    hands on as ``saved[1]``); for the region form the pair (destination order, source order) = ``saved[1]``,
+    ``saved[6]``.  (The graph's own sorted copies, never copies of them: a batch refilled in place rewrites them.)"""
     if not plan.region_nodes:
         return graph.sorted_edge_attr(edge_attr, dtype, "dst")[0]
-    ea_s, ea_t = graph.sorted_edge_attr(edge_attr, dtype)
-    hit = graph._scratch.get("region_ea")
-    if hit is None or hit[0] is not ea_s or hit[1] is not ea_t:     # (the cached pair is the same two objects)
-        hit = (ea_s, ea_t, torch.stack([ea_s, ea_t]))
-        graph._scratch["region_ea"] = hit
-    return hit[2]
+    return graph.sorted_edge_attr(edge_attr, dtype)
 
 
 def _region_forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, keep: bool):
     n = x.size(0)
     x, _, w_nodes, w_edge, w_out = _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph)
-    both = sorted_attr(plan, graph, edge_attr, x.dtype)
+    ea_s, ea_t = sorted_attr(plan, graph, edge_attr, x.dtype)
     lib = _lib.load()
     y = torch.empty((n, w_out.size(0)), dtype=x.dtype, device=x.device)
     # the sums over incoming edges, kept for the backward (which would otherwise walk the edges once more)
     aggr = torch.empty((n, w_out.size(0)), dtype=torch.float32, device=x.device) if keep else None
-    d = _desc(plan, graph, x, both[0], w_nodes, w_edge, w_out, y)
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y)
     with _Timed("region_layer_fwd", x.device):
         _lib.check(lib.mpnn_region_layer_fwd(ctypes.byref(d), plan.region_nodes, _lib.ptr(aggr),
                                              _lib.stream_handle(x.device)), "mpnn_region_layer_fwd")
-    return y, None, (x, both, w_nodes, w_edge, w_out, aggr, None)
+    return y, None, (x, ea_s, w_nodes, w_edge, w_out, aggr, ea_t)
 
 
 def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs):
-    x, both, w_nodes, w_edge, w_out = saved[:5]
-    aggr = saved[5] if len(saved) > 5 else None
+    x, ea_s, w_nodes, w_edge, w_out, aggr, ea_t = saved
     if aggr is not None and (aggr.dtype != torch.float32 or not aggr.is_contiguous()):
         aggr = None                                   # (recomputed)
-    ea_s, ea_t = both[0], both[1]
     need_x, need_wn, need_we, need_wout = needs
     lib = _lib.load()
     dev, dt = x.device, x.dtype

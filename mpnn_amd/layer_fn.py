@@ -54,8 +54,9 @@ def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: boo
         cnt = (torch.empty((n, h), dtype=torch.uint8, device=x.device), None) if want else None
         width = (3 if fused_x(x.dtype, f, h) else 2) * h      # the shape the general path would return
         # (the point-cloud form keeps its sums for the backward, in float32)
-        aggr = saved[5] if saved[5] is not None and saved[5].dtype == x.dtype else x.new_empty((n, h))
-        return y, x.new_empty((n, width)), aggr, cnt, None, saved[1]
+        region = plan.region_nodes > 0
+        aggr = saved[5] if region and saved[5] is not None and saved[5].dtype == x.dtype else x.new_empty((n, h))
+        return y, x.new_empty((n, width)), aggr, cnt, None, ((saved[1], saved[6]) if region else saved[1])
     fused = fused_x(x.dtype, f, h) and x.data_ptr() % 16 == 0
     if fused:
         ab = gemm_nt(x, torch.cat([w_nodes, w_out[:, :f]], dim=0))     # [A | B | P], P = x Wx^T
@@ -84,8 +85,11 @@ def backward_impl(gy, x, ab, aggr, cnt, maskbits, y, ea_t, w_nodes, w_edge, w_ou
     h = w_out.size(0)
     plan = islands.plan_for(graph, f, h, w_edge.size(1), False)
     if plan is not None:   # the choice forward_impl made: it depends on the graph and the shapes only
-        kept = aggr if plan.region_nodes and aggr.dtype == torch.float32 else None
-        saved = (x, ea_t, w_nodes.contiguous(), w_edge.contiguous(), w_out.contiguous(), kept, None)
+        if plan.region_nodes:      # ea_t: the pair (destination order, source order), see islands.sorted_attr
+            kept = aggr if aggr.dtype == torch.float32 else None
+            saved = (x, ea_t[0], w_nodes.contiguous(), w_edge.contiguous(), w_out.contiguous(), kept, ea_t[1])
+        else:
+            saved = (x, ea_t, w_nodes.contiguous(), w_edge.contiguous(), w_out.contiguous(), None, None)
         return islands.backward(plan, graph, gy, y, saved, needs)[:4]
     w_edge = w_edge.contiguous()
     gy = gy if gy.is_contiguous() else gy.contiguous()
@@ -156,7 +160,7 @@ class _LayerFn(torch.autograd.Function):
         if ctx.plan is not None:   # the whole layer in one launch; the backward recomputes the intermediates
             y, _, saved = islands.forward(ctx.plan, graph, x, edge_attr, w_nodes, w_edge, w_out, keep=want)
             if want:
-                ctx.save_for_backward(y, *saved[:6])
+                ctx.save_for_backward(y, *saved)
                 ctx.graph = graph
             return y
         y, ab, aggr, cnt, maskbits, ea_t = forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph, want)
@@ -170,7 +174,7 @@ class _LayerFn(torch.autograd.Function):
         needs = tuple(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
         if ctx.plan is not None:
             y, *saved = ctx.saved_tensors
-            gx, g_wn, g_we, g_wout = islands.backward(ctx.plan, ctx.graph, gy, y, tuple(saved) + (None,), needs)[:4]
+            gx, g_wn, g_we, g_wout = islands.backward(ctx.plan, ctx.graph, gy, y, tuple(saved), needs)[:4]
             return gx, None, g_wn, g_we, g_wout, None
         x, ab, aggr, cnt8, cnt_big, maskbits, y, ea_t, w_nodes, w_edge, w_out = ctx.saved_tensors
         gx, g_wn, g_we, g_wout = backward_impl(gy, x, ab, aggr, (cnt8, cnt_big), maskbits, y, ea_t, w_nodes, w_edge, w_out,

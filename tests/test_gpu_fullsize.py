@@ -43,7 +43,10 @@ def test_layer_sum_full_size_against_torch_gpu(workload):
     want_out.backward(r)
     want = [want_out.detach(), xr.grad] + [w.grad for w in ws]
     for name, g, w in zip(("out", "grad x", "grad fused_linear", "grad linear_3", "grad linear_out"), got, want):
-        assert_close(g, w, RTOL32, atol_scale=4.0, what=f"{workload}: {name}", kink_frac=1e-5)
+        # both sides are float32 evaluations: where a message's pre-activation is zero to rounding the relu may fall
+        # on either side, and one such edge moves the input gradient of its two end rows by a whole term (expected
+        # about once per 4e7 edge-column pairs, i.e. once on the point-cloud batch): a handful of entries may differ
+        assert_close(g, w, RTOL32, atol_scale=4.0, what=f"{workload}: {name}", kink_frac=2e-4 if name == "grad x" else 1e-5)
 
     # determinism: a second run is bitwise identical (no atomics anywhere in the HIP path)
     for p in layer.parameters():
