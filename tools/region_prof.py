@@ -23,14 +23,15 @@ w = [p.detach() for p in (layer.fused_linear.weight, layer.linear_3.weight, laye
 gy = torch.randn(x.size(0), h, device=dev)
 
 
-def report(name, slots):
+def report(name, first, last):
+    """Phases first+1 .. last of the timestamps (slot `first` is the reference point)."""
     t = buf.cpu().double() * 0.01   # 100 MHz ticks -> us
-    live = t[:, 0] > 0
+    live = t[:, first] > 0
     t = t[live]
-    start = t[:, 0].min()
-    print(f"{name}: {int(live.sum())} waves, first start -> last end {float(t[:, slots - 1].max() - start):.1f} us, "
-          f"start spread {float(t[:, 0].max() - start):.1f} us")
-    for k in range(1, slots):
+    start = t[:, first].min()
+    print(f"{name}: {int(live.sum())} waves, first start -> last end {float(t[:, last].max() - start):.1f} us, "
+          f"start spread {float(t[:, first].max() - start):.1f} us")
+    for k in range(first + 1, last + 1):
         dt = t[:, k] - t[:, k - 1]
         print(f"   phase {k:2d}: mean {float(dt.mean()):7.2f} us   max {float(dt.max()):7.2f}")
 
@@ -43,11 +44,12 @@ lib.mpnn_island_prof_buffer(buf.data_ptr())
 buf.zero_()
 y, _, saved = islands.forward(plan, graph, x, ea, *w)
 torch.cuda.synchronize()
-report("forward (table+weights | walk | zero+aggr+sync | update | store)", 6)
+report("forward (1 loads + barrier | 2 edge walk | 3 zero rows, keep sums, barrier | 4 update product | 5 store)", 0, 5)
 # the backward's three kernels write the same slots: profile them one at a time by what they leave
 buf.zero_()
 islands.backward(plan, graph, gy, y, saved, (True, True, True, True))
 torch.cuda.synchronize()
-print("backward: slots 0-3 are overwritten by the pass over the sources (it runs second); 4-8 belong to the first pass")
-report("backward", 9)
+# the pass over the sources runs second and writes slots 0-3 again: the first pass is reported from slot 4 on
+report("backward, destination tiles (5 ga to memory | 6 edge walk | 7 barrier | 8 weight-gradient shares)", 4, 8)
+report("backward, source rows (1 loads + barrier | 2 edge walk | 3 weight-gradient shares)", 0, 3)
 lib.mpnn_island_prof_buffer(None)
