@@ -1373,7 +1373,7 @@ constexpr int kRegionWp = kRegionF + kRegionH;   // row of the update weight in 
 __host__ __device__ inline int64_t region_lds_floats(int cap, bool backward) {
   const int px = island_pitch(kRegionF + kRegionH), pz = island_pitch(kRegionH);
   return kIslandHeader + (int64_t)kRegionF * cap + kRegionTiles * kTileRows * (px + (backward ? pz : 0)) +
-         kRegionH * kRegionWp;
+         kRegionH * kRegionWp + (backward ? 2 * kRegionH * kRegionH : 0);
 }
 
 // W_out [H, F + H] into LDS as float rows of 68 with the x part padded to 4 columns: the tile's rows [x | 0 | aggr]
@@ -1483,6 +1483,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
   float* ag = xa + kRegionF;
   float* gz = xa + o_gz;
   float* wl = tiles + kRegionTiles * tile_floats;
+  float* meet = wl + kRegionH * kRegionWp;   // [2][H][H]: the two halves of gW_out's aggr part
   const RegionBlock rb = region_block(a.island_ptr, ra.groups, ra.cap, blockIdx.x);
   if (!rb.live) return;   // whole block; k_region_reduce skips its slab
   float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
@@ -1503,14 +1504,35 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     const T* gy = static_cast<const T*>(a.gy);
     const T* y = static_cast<const T*>(a.y);
     const int64_t ldy = a.ldy, ldgy = a.ldgy;
+    const bool wide = ldy % 4 == 0 && ldgy % 4 == 0 && (((uintptr_t)gy | (uintptr_t)y) & 15) == 0;   // (uniform)
+    if (wide) {   // 4 columns per lane and load, all eight loads of a lane in flight together
+      float4 yv[4], gv[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, r = r0 + i / (H / 4), c = 4 * (i % (H / 4));
+        const int rc = r < tn ? r : (tn > 0 ? tn - 1 : 0);
+        const int64_t node = tn > 0 ? n_first + rc : rb.n0;
+        yv[k] = load4<T>(y + node * ldy + c);
+        gv[k] = load4<T>(gy + node * ldgy + c);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, r = r0 + i / (H / 4), c = 4 * (i % (H / 4));
+        const bool in = r < tn;
+        *reinterpret_cast<float4*>(gz + r * pz + c) =
+            make_float4(in && yv[k].x > 0.f ? gv[k].x : 0.f, in && yv[k].y > 0.f ? gv[k].y : 0.f,
+                        in && yv[k].z > 0.f ? gv[k].z : 0.f, in && yv[k].w > 0.f ? gv[k].w : 0.f);
+      }
+    } else {
 #pragma unroll 8
-    for (int i = lane; i < 16 * H; i += 64) {
-      const int r = r0 + i / H, c = i & (H - 1);
-      const int rc = r < tn ? r : (tn > 0 ? tn - 1 : 0);
-      const int64_t node = tn > 0 ? n_first + rc : rb.n0;
-      const float yv = scalar_to_f32<T>(y[node * ldy + c]);
-      const float gv = scalar_to_f32<T>(gy[node * ldgy + c]);
-      gz[r * pz + c] = (r < tn && yv > 0.f) ? gv : 0.f;
+      for (int i = lane; i < 16 * H; i += 64) {
+        const int r = r0 + i / H, c = i & (H - 1);
+        const int rc = r < tn ? r : (tn > 0 ? tn - 1 : 0);
+        const int64_t node = tn > 0 ? n_first + rc : rb.n0;
+        const float yv = scalar_to_f32<T>(y[node * ldy + c]);
+        const float gv = scalar_to_f32<T>(gy[node * ldgy + c]);
+        gz[r * pz + c] = (r < tn && yv > 0.f) ? gv : 0.f;
+      }
     }
   }
   region_table<T>(xs, a, rb);
@@ -1534,45 +1556,59 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
   for (int i = lane; i < (16 - nr) * H; i += 64) ag[(r0 + nr + i / H) * px + (i & (H - 1))] = 0.f;
   __syncthreads();
   REGION_PROF(2);
-  // gW_out = gz^T [x | aggr] over the rows of the whole block
+  // gW_out's aggr part = gz^T aggr over the rows of the whole block: 2 x 2 output tiles of 32 x 32, the contraction
+  // over the block's four row tiles cut in two, so that each of the 8 waves multiplies one output tile over two row
+  // tiles; the halves meet in LDS.  (The x part, F columns, is collected by the edge walk below.)
   {
-    const int ktiles = (F + H + 31) / 32;
-    const int tasks = (H / 32) * ktiles;
-    for (int t = w; t < tasks; t += kRegionWaves)
-      block_outer<T, false>(part, F + H, 32 * (t / ktiles), 32 * (t % ktiles), tiles, tile_floats, nrows, n0s,
-                            kRegionTiles, o_gz, pz, 0, px, F, kRegionF - F, static_cast<const T*>(a.x), a.ldx, li, lh);
+    const int c0 = 32 * (w & 1), col0 = 32 * ((w >> 1) & 1), pp = w >> 2;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int w2 = 2 * pp; w2 < 2 * pp + 2; ++w2) {
+      const float* tb = tiles + w2 * tile_floats;
+      const int nr2 = nrows[w2];
+      if (nr2 == 0) continue;
+      float av[16], bv[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = 2 * q + lh;
+        av[q] = tb[o_gz + row * pz + c0 + li];
+        bv[q] = tb[row * px + kRegionF + col0 + li];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        if (2 * q < nr2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+    }
+    float* st = meet + pp * H * H;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) st[(c0 + acc_row(i, lh)) * H + col0 + li] = acc[i];
   }
   __syncthreads();
+  for (int e = threadIdx.x; e < H * H; e += blockDim.x) part[(e / H) * (F + H) + F + (e & (H - 1))] = meet[e] + meet[H * H + e];
   REGION_PROF(3);
-  // [first part of gx | ga] = gz W_out, the pair taking alternate pieces of 64 columns; both replace their
-  // operands of the product above in the tile
-  // (the weight rows in LDS have the tile's column layout: a result column is a tile column; the pad columns of
-  // the x part come out as zeros)
+  // ga = gz Wa (the aggr columns of W_out), each wave of the pair one tile of 32 columns; it replaces the sums in
+  // the tile.  (gz Wx, the first part of gx, is formed per row in the walk.)
   if (tn > 0) {
-    for (int col0 = 64 * half; col0 < kRegionWp; col0 += 128) {
-      f32x16 acc[2];
+    f32x16 acc[1];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-      mm_w<float, 2>(acc, gz, pz, H, wl, kRegionWp, col0, kRegionWp, li, lh);
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int col = col0 + 32 * t + li;
-        if (col >= kRegionWp) continue;
-        for_acc(acc[t], lh, [&](int row, float v) __attribute__((always_inline)) { xa[row * px + col] = v; });
-      }
-    }
+    for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
+    mm_w<float, 1>(acc, gz, pz, H, wl, kRegionWp, kRegionF + 32 * half, kRegionWp, li, lh);
+    for_acc(acc[0], lh, [&](int row, float v) __attribute__((always_inline)) { ag[row * px + 32 * half + li] = v; });
   }
+  f32x2 wx[2][FW];   // the lane's rows of the x part of W_out
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int f = 0; f < FW; ++f) wx[j >> 1][f][j & 1] = wl[(4 * l + j) * kRegionWp + f];
   __syncthreads();
   REGION_PROF(4);
-  f32x2 gwe[2][FEW], gwa[2][FW];
+  f32x2 gwe[2][FEW], gwa[2][FW], gwx[2][FW];
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
 #pragma unroll
     for (int d = 0; d < FEW; ++d) gwe[p][d] = (f32x2)(0.f);
 #pragma unroll
-    for (int f = 0; f < FW; ++f) gwa[p][f] = (f32x2)(0.f);
+    for (int f = 0; f < FW; ++f) gwa[p][f] = gwx[p][f] = (f32x2)(0.f);
   }
   if (nr > 0) {
     // ga of this wave's rows for the pass over the sources
@@ -1582,7 +1618,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
           *reinterpret_cast<const float4*>(ag + (r0 + r) * px + c);
     }
     REGION_PROF(5);
-    f32x2 av[2], gar[2], ga_sum[2];
+    f32x2 av[2], gar[2], gzr[2], ga_sum[2];
     float xr[FW];
     float* const gx_part = a.gx ? a.gx_part : nullptr;
     thin_walk<T, FEW, FW, false>(
@@ -1596,6 +1632,9 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
           const float4 g4 = *reinterpret_cast<const float4*>(ag + rr * px + 4 * l);
           gar[0] = f32x2{g4.x, g4.y};
           gar[1] = f32x2{g4.z, g4.w};
+          const float4 z4 = *reinterpret_cast<const float4*>(gz + rr * pz + 4 * l);
+          gzr[0] = f32x2{z4.x, z4.y};
+          gzr[1] = f32x2{z4.z, z4.w};
 #pragma unroll
           for (int p = 0; p < 2; ++p) { av[p] = tw.a_of(p, xr); ga_sum[p] = (f32x2)(0.f); }
         },
@@ -1612,14 +1651,18 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
           }
         },
         [&](int r, bool ok) __attribute__((always_inline)) {
-          // ga_sum = gradient of A[r]: its share of gWn, and of gx[r] through the A half of the node weight
+          // ga_sum = gradient of A[r]: its share of gWn and of gx[r]; gz[r]: its share of gW_out's x part and of gx[r]
           float mine = 0.f;
 #pragma unroll
           for (int f = 0; f < FW; ++f) {
             f32x2 t2 = (f32x2)(0.f);
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-              if (ok) gwa[p][f] = fma2(ga_sum[p], xr[f], gwa[p][f]);
+              if (ok) {
+                gwa[p][f] = fma2(ga_sum[p], xr[f], gwa[p][f]);
+                gwx[p][f] = fma2(gzr[p], xr[f], gwx[p][f]);
+              }
+              t2 = __builtin_elementwise_fma(gzr[p], wx[p][f], t2);
               t2 = __builtin_elementwise_fma(ga_sum[p], tw.wa[p][f], t2);
             }
             if (gx_part) {
@@ -1627,7 +1670,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
               mine = l == f ? v : mine;
             }
           }
-          if (gx_part && ok && l < F) gx_part[(int64_t)(n_first + r0 + r) * F + l] = xa[(r0 + r) * px + l] + mine;
+          if (gx_part && ok && l < F) gx_part[(int64_t)(n_first + r0 + r) * F + l] = mine;
         });
   }
   REGION_PROF(6);
@@ -1648,16 +1691,24 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
 #pragma unroll
       for (int f = 0; f < FW; ++f) {
         const float v = across_groups(gwa[j >> 1][f][j & 1], lane);
-        if (lane < 16 && f < F) slab[H * a.Fe + c * F + f] = v;
+        const float u = across_groups(gwx[j >> 1][f][j & 1], lane);
+        if (lane < 16 && f < F) {
+          slab[H * a.Fe + c * F + f] = v;
+          slab[H * (a.Fe + F) + c * F + f] = u;
+        }
       }
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < H * (a.Fe + F); e += blockDim.x) {
+  for (int e = threadIdx.x; e < H * (a.Fe + 2 * F); e += blockDim.x) {
     float t = 0.f;
     for (int w2 = 0; w2 < kRegionWaves; ++w2) t += tiles[(w2 >> 1) * tile_floats + o_gz + (w2 & 1) * 16 * pz + e];
     if (e < H * a.Fe) part[o_we + e] = t;
-    else part[o_wn + (e - H * a.Fe)] = t;
+    else if (e < H * (a.Fe + F)) part[o_wn + (e - H * a.Fe)] = t;
+    else {   // gW_out[c][f], f < F
+      const int i = e - H * (a.Fe + F);
+      part[(i / F) * (F + H) + i % F] = t;
+    }
   }
   REGION_PROF(8);
 }
@@ -1678,12 +1729,12 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
   if (!rb.live) return;
   float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
   const int64_t o_wnb = (int64_t)H * (F + H) + (int64_t)H * F;
-  REGION_PROF(0);
+  REGION_PROF(9);
   ThinWeights<T, FEW, FW> tw;
   tw.load(a, lane);
   region_table<T>(xs, a, rb);
   __syncthreads();
-  REGION_PROF(1);
+  REGION_PROF(10);
   const int s0 = rb.base + 16 * w;
   const int nr = rb.rn - s0 < 16 ? (rb.rn - s0 < 0 ? 0 : rb.rn - s0) : 16;
   f32x2 gwb[2][FW];
@@ -1741,7 +1792,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
           }
         });
   }
-  REGION_PROF(2);
+  REGION_PROF(11);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1755,7 +1806,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
     for (int w2 = 0; w2 < kRegionWaves; ++w2) t += slabs[w2 * H * kRegionF + e];
     part[o_wnb + e] = t;
   }
-  REGION_PROF(3);
+  REGION_PROF(12);
 }
 
 // Sums the live blocks' partials in a fixed order: a thread takes one element and every sixteenth block in

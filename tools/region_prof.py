@@ -49,7 +49,7 @@ report("forward (1 loads + barrier | 2 edge walk | 3 zero rows, keep sums, barri
 buf.zero_()
 islands.backward(plan, graph, gy, y, saved, (True, True, True, True))
 torch.cuda.synchronize()
-# the pass over the sources runs second and writes slots 0-3 again: the first pass is reported from slot 4 on
-report("backward, destination tiles (5 ga to memory | 6 edge walk | 7 barrier | 8 weight-gradient shares)", 4, 8)
-report("backward, source rows (1 loads + barrier | 2 edge walk | 3 weight-gradient shares)", 0, 3)
+report("backward, destination tiles (1 loads, gz, barrier | 2 kept sums, barrier | 3 gW_out tiles, barrier | 4 gz W_out, barrier | "
+       "5 ga to memory | 6 edge walk | 7 barrier | 8 weight-gradient shares)", 0, 8)
+report("backward, source rows (10 loads + barrier | 11 edge walk | 12 weight-gradient shares)", 9, 12)
 lib.mpnn_island_prof_buffer(None)
