@@ -1167,14 +1167,15 @@ struct ThinWeights {
     for (int f = 1; f < FW; ++f) s = fma2(wb[p][f], x[f], s);
     return s;
   }
-  // the message before its relu, associated as the reference does: (A[dst] + B[src]) + We . e
-  // (models/layers.py:128), the edge term a chain of multiply-adds in feature order - the same operations in the
-  // same order wherever it is computed, so that every pass sees the same bits
+  // the message before its relu: (A[dst] + B[src]) as in the reference (models/layers.py:128), then the edge term
+  // We . e added to it one multiply-add per edge feature, in feature order.  Written out as explicit multiply-adds
+  // (nothing left to the compiler's contraction), so that the same bits come out wherever it is computed and the
+  // passes agree on every relu decision.
   __device__ __forceinline__ f32x2 pre(int p, f32x2 a, f32x2 b, const float (&ev)[FEW]) const {
-    f32x2 es = we[p][0] * ev[0];
+    f32x2 t = a + b;
 #pragma unroll
-    for (int d = 1; d < FEW; ++d) es = fma2(we[p][d], ev[d], es);
-    return (a + b) + es;
+    for (int d = 0; d < FEW; ++d) t = fma2(we[p][d], ev[d], t);
+    return t;
   }
 };
 
