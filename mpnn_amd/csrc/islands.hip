@@ -815,13 +815,28 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
     const T* gy = static_cast<const T*>(a.gy);
     const T* y = static_cast<const T*>(a.y);
     const int64_t ldy = a.ldy, ldgy = a.ldgy;
+    const bool wide = ldy % 4 == 0 && ldgy % 4 == 0 && (((uintptr_t)gy | (uintptr_t)y) & 15) == 0;   // (uniform)
+    if (wide) {   // 4 columns per lane and load; the loads of 8 steps (both arrays) are in flight together
 #pragma unroll 8
-    for (int i = lane; i < kTileRows * H; i += 64) {   // both loads unconditional (row clamped): all in flight together
-      const int r = i / H, c = i & (H - 1);
-      const int rc = r < n ? r : n - 1;
-      const float yv = scalar_to_f32<T>(y[(int64_t)(n0 + rc) * ldy + c]);
-      const float gv = scalar_to_f32<T>(gy[(int64_t)(n0 + rc) * ldgy + c]);
-      gz[r * pz + c] = (r < n && yv > 0.f) ? gv : 0.f;
+      for (int i = lane; i < kTileRows * (H / 4); i += 64) {
+        const int r = i / (H / 4), c = 4 * (i % (H / 4));
+        const int rc = r < n ? r : n - 1;
+        const float4 yv = load4<T>(y + (int64_t)(n0 + rc) * ldy + c);
+        const float4 gv = load4<T>(gy + (int64_t)(n0 + rc) * ldgy + c);
+        const bool in = r < n;
+        *reinterpret_cast<float4*>(gz + r * pz + c) =
+            make_float4(in && yv.x > 0.f ? gv.x : 0.f, in && yv.y > 0.f ? gv.y : 0.f, in && yv.z > 0.f ? gv.z : 0.f,
+                        in && yv.w > 0.f ? gv.w : 0.f);
+      }
+    } else {
+#pragma unroll 8
+      for (int i = lane; i < kTileRows * H; i += 64) {   // both loads unconditional (row clamped): all in flight together
+        const int r = i / H, c = i & (H - 1);
+        const int rc = r < n ? r : n - 1;
+        const float yv = scalar_to_f32<T>(y[(int64_t)(n0 + rc) * ldy + c]);
+        const float gv = scalar_to_f32<T>(gy[(int64_t)(n0 + rc) * ldgy + c]);
+        gz[r * pz + c] = (r < n && yv > 0.f) ? gv : 0.f;
+      }
     }
     wave_sync();
     if ((int)blockIdx.x * wpb + w >= a.n_islands) {
