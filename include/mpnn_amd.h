@@ -40,7 +40,7 @@ enum {
   MPNN_E_CAPACITY = -4   /* an output array's stated capacity is too small */
 };
 
-#define MPNN_ABI_VERSION 16
+#define MPNN_ABI_VERSION 17
 
 /* Library self-description. */
 int32_t mpnn_abi_version(void);
@@ -562,22 +562,25 @@ int32_t mpnn_island_layer_bwd(const mpnn_island_layer* desc, mpnn_stream_t strea
  * The k-NN batches of the point-cloud workload (experiments/modelnet_exp.py:58, `data.pos` as x) are islands of a
  * thousand nodes with 3 input features.  The x of a whole island then fits the LDS, and the projection rows of an
  * edge's two ends (models/layers.py:104-105) are recomputed from it per edge instead of being fetched: the forward
- * of MPNNLayerSum is ONE launch (projection, messages, sums, update), the backward three (destination tiles,
+ * of MPNNLayerSum (or of the EGNN layer) is ONE launch (projection, messages, sums, update), the backward three (destination tiles,
  * source rows, fixed-order sum of the per-block weight-gradient partials).  Results are deterministic and agree
  * with the general path to rounding.
  *
- * The descriptor is the one of the island layers with rows = 32, tail_units = 0 (the islands cover every node),
- * pos = NULL.  Limits: H = 64, 1 <= F <= 4, 1 <= Fe <= 8, max_nodes (a bound on the largest island) <= 2048;
- * mpnn_region_layer_fits(...) tells.  The backward also reads the source-sorted view (rowptr_t [N + 1], col_t [E]:
- * destinations of the edges grouped by source; ea_t [E, Fe] in that order, `dtype`) and needs
+ * The descriptor is the one of the island layers with rows = 32, tail_units = 0 (the islands cover every node).
+ * With pos (and w_pos, pos_out; gpos_out, gpos, g_wpos in the backward) the calls run the EGNN layer, as the island
+ * entry points do.  Limits: H = 64, 1 <= F <= 4, 1 <= Fe <= 8, max_nodes (a bound on the largest island) <= 2048
+ * (<= 1024 with coordinates: their tables share the LDS); mpnn_region_layer_fits(...) tells.  The backward also reads
+ * the source-sorted view (rowptr_t [N + 1], col_t [E]: destinations of the edges grouped by source; ea_t [E, Fe] in
+ * that order, `dtype`) and needs
  *   partial   mpnn_region_layer_partial_floats(...) floats of scratch
  *   gx_part   float [N, F] scratch (only when gx is given)
- *   ga        float [N, H] scratch
+ *   ga        float [N, H] scratch, N more floats behind it when pos is given
  *   aggr      float [N, H]: the sums over incoming edges, written by the forward when given and handed to the
  *             backward, which otherwise (NULL) walks the edges once more to recompute them
  * ------------------------------------------------------------------------- */
-int32_t mpnn_region_layer_fits(int32_t F, int32_t H, int32_t Fe, int32_t max_nodes);
-int64_t mpnn_region_layer_partial_floats(int32_t n_islands, int32_t max_nodes, int32_t F, int32_t H, int32_t Fe);
+int32_t mpnn_region_layer_fits(int32_t F, int32_t H, int32_t Fe, int32_t max_nodes, int32_t egnn);
+int64_t mpnn_region_layer_partial_floats(int32_t n_islands, int32_t max_nodes, int32_t F, int32_t H, int32_t Fe,
+                                         int32_t egnn);
 int32_t mpnn_region_layer_fwd(const mpnn_island_layer* desc, int32_t max_nodes, float* aggr, mpnn_stream_t stream);
 int32_t mpnn_region_layer_bwd(const mpnn_island_layer* desc, int32_t max_nodes, const int32_t* rowptr_t,
                               const int32_t* col_t, const void* ea_t, const float* aggr, float* ga,

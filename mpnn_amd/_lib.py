@@ -14,7 +14,7 @@ import torch  # noqa: F401  (loads the HIP runtime the library binds to)
 MPNN_F32 = 0
 MPNN_BF16 = 1
 MPNN_U8 = 2
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 LIB_PATH = os.environ.get("MPNN_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmpnn_amd.so")
 
@@ -64,8 +64,8 @@ SIGNATURES = {
     "mpnn_island_layer_partial_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "mpnn_island_layer_fwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_void_p]),
     "mpnn_island_layer_bwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_void_p]),
-    "mpnn_region_layer_fits": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
-    "mpnn_region_layer_partial_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mpnn_region_layer_fits": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "mpnn_region_layer_partial_floats": (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "mpnn_region_layer_fwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_int32, c_void_p, c_void_p]),
     "mpnn_region_layer_bwd": (c_int32, [ctypes.POINTER(IslandLayerDesc), c_int32, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),

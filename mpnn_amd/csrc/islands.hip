@@ -1128,6 +1128,7 @@ struct RegionLayer {
   const int32_t* rowptr_t; const int32_t* col_t; const void* ea_t;   // source-sorted view
   float* ga;        // [N, H] gradient arriving at the sums
   float* aggr;      // [N, H] the sums: written by the forward, read by the backward (null: not kept / recomputed)
+  float* srow;      // [N] EGNN backward: w_pos . aggr[n], from the first pass to the second
 };
 
 struct RegionBlock { int n0, rn, base; bool live; };   // island [n0, n0 + rn), the block's rows start at local row base
@@ -1154,12 +1155,15 @@ __device__ __forceinline__ f32x2 fma2(f32x2 a, float b, f32x2 c) {   // v_pk_fma
 template <typename T, int FEW, int FW>
 struct ThinWeights {
   f32x2 wa[2][FW], wb[2][FW], we[2][FEW];
+  f32x2 wp[2];   // the coordinate weight (EGNN form; zeros otherwise)
   __device__ __forceinline__ void load(const IslandLayer& a, int lane) {
     const T* wn = static_cast<const T*>(a.w_nodes);
     const T* w = static_cast<const T*>(a.w_edge);
+    const T* wpos = static_cast<const T*>(a.w_pos);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = 4 * (lane & 15) + j;
+      wp[j >> 1][j & 1] = wpos ? scalar_to_f32<T>(wpos[c]) : 0.f;
 #pragma unroll
       for (int f = 0; f < FW; ++f) {
         wa[j >> 1][f][j & 1] = f < a.F ? scalar_to_f32<T>(wn[c * a.F + f]) : 0.f;
@@ -1194,11 +1198,11 @@ struct ThinWeights {
   }
 };
 
-// The island's rows of x as a table of 4 floats per node.  (Eight loads per thread are requested before the first
-// is stored: a loop of load-then-store would pay one trip to memory per iteration.)
-template <typename T>
-__device__ __forceinline__ void region_table(float* xs, const IslandLayer& a, const RegionBlock& rb) {
-  const T* x = static_cast<const T*>(a.x);
+// The island's rows of a [N, width <= 4] array as a table of 4 floats per node (zeros past the width).  (Eight loads
+// per thread are requested before the first is stored: a loop of load-then-store would pay one trip to memory per
+// iteration.)
+template <typename S>
+__device__ __forceinline__ void region_rows(float* xs, const S* x, int64_t ld, int width, const RegionBlock& rb) {
   const int total = rb.rn * kRegionF;
   for (int i0 = threadIdx.x; i0 < total; i0 += 8 * blockDim.x) {
     float v[8];
@@ -1207,8 +1211,8 @@ __device__ __forceinline__ void region_table(float* xs, const IslandLayer& a, co
       const int i = i0 + k * blockDim.x;
       const int ic = i < total ? i : 0;
       const int r = ic >> 2, f = ic & 3;
-      const float t = scalar_to_f32<T>(x[(int64_t)(rb.n0 + r) * a.ldx + (f < a.F ? f : 0)]);
-      v[k] = f < a.F ? t : 0.f;
+      const float t = scalar_to_f32<S>(x[(int64_t)(rb.n0 + r) * ld + (f < width ? f : 0)]);
+      v[k] = f < width ? t : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -1216,6 +1220,10 @@ __device__ __forceinline__ void region_table(float* xs, const IslandLayer& a, co
       if (i < total) xs[i] = v[k];
     }
   }
+}
+template <typename T>
+__device__ __forceinline__ void region_table(float* xs, const IslandLayer& a, const RegionBlock& rb) {
+  region_rows<T>(xs, static_cast<const T*>(a.x), a.ldx, a.F, rb);
 }
 
 __device__ __forceinline__ float group_value(float v, int byte_addr) {   // v of the lane at byte_addr / 4
@@ -1240,10 +1248,11 @@ __device__ __forceinline__ float across_groups(float v, int lane) {
   return v + group_value(v, 4 * (lane ^ 32));
 }
 
-template <int FEW, int FW, bool GATHER>
+template <int FEW, int FW, bool GATHER, int NX>
 struct ThinEdges {   // four consecutive edges of a group's row
   float x[4][FW], e[4][FEW];
-  float4 g[4];       // GATHER: the lane's columns of the gradient row of the edge's other end
+  float p[4][NX > 0 ? NX : 1][3];   // the other end's rows of the NX further node tables (3 values each)
+  float4 g[4];                      // GATHER: the lane's columns of the gradient row of the edge's other end
 };
 
 template <int FEW>
@@ -1256,10 +1265,14 @@ struct ThinPiece { int c[2]; float e[2][FEW]; };   // 32 edges of a group's row:
 // values are finite and must not count), and with GATHER the lane's four columns of gather[other end]; end(r, ok)
 // when the row is complete.  The lanes of a group see the same arguments.  The index and attribute reads of the
 // piece after the one being walked - of the next four rows, when this is the rows' last - are in flight meanwhile.
-template <typename T, int FEW, int FW, bool GATHER, typename Begin, typename Edge, typename End>
+// NX further tables of 4 floats per node (xt0, xt1: coordinates, their gradient) hand the edge function the first
+// three values of the other end's row of each as its last argument.
+template <typename T, int FEW, int FW, bool GATHER, int NX = 0, typename Begin, typename Edge, typename End>
 __device__ __forceinline__ void thin_walk(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                           const T* __restrict__ ea, int Fe, const float* xs, int n0, int nr, int col_base,
-                                          int last, int lane, const float* gather, Begin begin, Edge edge, End end) {
+                                          int last, int lane, const float* gather, const float* xt0, const float* xt1,
+                                          Begin begin, Edge edge, End end) {
+  constexpr bool AHEAD = FEW == 1 && NX < 2;   // a second set of edge values, one group of four ahead, when it fits
   const int l = lane & 15, grp = lane >> 4;
   const int gbase = 4 * (lane & 48);   // byte address of the group's first lane for ds_bpermute
   const int rpv = rowptr[n0 + (lane < nr ? lane : nr)];   // lane i: where row i starts (i <= nr <= 16)
@@ -1304,7 +1317,7 @@ __device__ __forceinline__ void thin_walk(const int32_t* __restrict__ rowptr, co
       const ThinPiece<FEW> here = coming;
       int cnt = w.e1 - (w.e0 + 32 * p);
       cnt = cnt < 0 ? 0 : (cnt > 32 ? 32 : cnt);
-      float sx[2][FW];
+      float sx[2][FW], sp[2][NX > 0 ? NX : 1][3];
       int sc[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1315,11 +1328,16 @@ __device__ __forceinline__ void thin_walk(const int32_t* __restrict__ rowptr, co
         const float xa4[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
         for (int f = 0; f < FW; ++f) sx[h][f] = xa4[f];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) {
+          const float4 pv = *reinterpret_cast<const float4*>((t == 0 ? xt0 : xt1) + 4 * c);
+          sp[h][t][0] = pv.x; sp[h][t][1] = pv.y; sp[h][t][2] = pv.z;
+        }
       }
       if (p + 1 < w.pieces) coming = request(w, p + 1);
       else if (slot + 1 < slots && next_rows.pieces > 0) coming = request(next_rows, 0);
       const int kmax = wave_max4(cnt);
-      auto take = [&](int k0, ThinEdges<FEW, FW, GATHER>& t) __attribute__((always_inline)) {
+      auto take = [&](int k0, ThinEdges<FEW, FW, GATHER, NX>& t) __attribute__((always_inline)) {
         const bool hi = k0 >= 16;   // (uniform) which of the lane's two staged edges the four come from
         const int addr = gbase + 4 * (k0 & 15);
 #pragma unroll
@@ -1328,27 +1346,31 @@ __device__ __forceinline__ void thin_walk(const int32_t* __restrict__ rowptr, co
           for (int f = 0; f < FW; ++f) t.x[q][f] = group_value(hi ? sx[1][f] : sx[0][f], addr + 4 * q);
 #pragma unroll
           for (int d = 0; d < FEW; ++d) t.e[q][d] = group_value(hi ? here.e[1][d] : here.e[0][d], addr + 4 * q);
+#pragma unroll
+          for (int u = 0; u < NX; ++u)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) t.p[q][u][k] = group_value(hi ? sp[1][u][k] : sp[0][u][k], addr + 4 * q);
           if constexpr (GATHER) {
             const int node = __builtin_amdgcn_ds_bpermute(addr + 4 * q, hi ? sc[1] : sc[0]);
             t.g[q] = *reinterpret_cast<const float4*>(gather + (int64_t)node * kRegionH + 4 * l);
           }
         }
       };
-      if constexpr (FEW == 1) {
-        ThinEdges<FEW, FW, GATHER> cur, nxt;   // the next four edges' values are on their way while these are used
+      if constexpr (AHEAD) {
+        ThinEdges<FEW, FW, GATHER, NX> cur, nxt;   // the next four edges' values are on their way while these are used
         take(0, cur);
         for (int k0 = 0; k0 < kmax; k0 += 4) {
           if (k0 + 4 < kmax) take(k0 + 4, nxt);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) edge(cur.x[q], cur.e[q], k0 + q < cnt ? 1.f : 0.f, cur.g[q]);
+          for (int q = 0; q < 4; ++q) edge(cur.x[q], cur.e[q], k0 + q < cnt ? 1.f : 0.f, cur.g[q], cur.p[q]);
           cur = nxt;
         }
-      } else {   // (wide attributes: one set of edge values fits the registers)
+      } else {   // (wide attributes, two further tables: one set of edge values fits the registers)
         for (int k0 = 0; k0 < kmax; k0 += 4) {
-          ThinEdges<FEW, FW, GATHER> cur;
+          ThinEdges<FEW, FW, GATHER, NX> cur;
           take(k0, cur);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) edge(cur.x[q], cur.e[q], k0 + q < cnt ? 1.f : 0.f, cur.g[q]);
+          for (int q = 0; q < 4; ++q) edge(cur.x[q], cur.e[q], k0 + q < cnt ? 1.f : 0.f, cur.g[q], cur.p[q]);
         }
       }
     }
@@ -1359,13 +1381,18 @@ __device__ __forceinline__ void thin_walk(const int32_t* __restrict__ rowptr, co
 }
 
 // Sums of the messages into rows [row0, row0 + nr) of the island (local ids), written to sums[r * pitch + c] for
-// r = 0 .. nr - 1.
-template <typename T, int FEW, int FW>
+// r = 0 .. nr - 1.  EGNN: also pos'[n] = pos[n] + sum_e (pos[n] - pos[src e]) (w_pos . m_e), written to pos_out;
+// sum_e rel_e (w_pos . m_e) = sum_c w_pos[c] (sum_e rel_e m_e[c]), so the lane keeps the inner sums of its columns
+// and the sum over the columns is taken once per row.
+template <typename T, int FEW, int FW, bool EGNN>
 __device__ __forceinline__ void region_sums(const IslandLayer& a, const ThinWeights<T, FEW, FW>& tw, const float* xs,
-                                            const RegionBlock& rb, int row0, int nr, float* sums, int pitch, int lane) {
-  f32x2 av[2], sum[2];
-  thin_walk<T, FEW, FW, false>(
-      a.rowptr, a.col, static_cast<const T*>(a.ea), a.Fe, xs, rb.n0 + row0, nr, rb.n0, rb.rn - 1, lane, nullptr,
+                                            const float* ps, const RegionBlock& rb, int row0, int nr, float* sums, int pitch,
+                                            int lane) {
+  f32x2 av[2], sum[2], vv[2][3];
+  float pr[3] = {0.f, 0.f, 0.f};
+  float* const pos_out = a.pos_out;
+  thin_walk<T, FEW, FW, false, EGNN ? 1 : 0>(
+      a.rowptr, a.col, static_cast<const T*>(a.ea), a.Fe, xs, rb.n0 + row0, nr, rb.n0, rb.rn - 1, lane, nullptr, ps, nullptr,
       [&](int r, bool ok) __attribute__((always_inline)) {
         const float4 xr = *reinterpret_cast<const float4*>(xs + 4 * (row0 + (ok ? r : 0)));
         const float x4[4] = {xr.x, xr.y, xr.z, xr.w};
@@ -1374,22 +1401,55 @@ __device__ __forceinline__ void region_sums(const IslandLayer& a, const ThinWeig
         for (int f = 0; f < FW; ++f) xv[f] = x4[f];
 #pragma unroll
         for (int p = 0; p < 2; ++p) { av[p] = tw.a_of(p, xv); sum[p] = (f32x2)(0.f); }
-      },
-      [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&) __attribute__((always_inline)) {
+        if constexpr (EGNN) {
+          const float4 p4 = *reinterpret_cast<const float4*>(ps + 4 * (row0 + (ok ? r : 0)));
+          pr[0] = p4.x; pr[1] = p4.y; pr[2] = p4.z;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-          sum[p] = fma2(__builtin_elementwise_max(tw.pre(p, av[p], tw.b_of(p, xv), ev), (f32x2)(0.f)), live, sum[p]);
+          for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vv[p][k] = (f32x2)(0.f);
+        }
+      },
+      [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&, const float (&ex)[1][3])
+          __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const f32x2 m = __builtin_elementwise_max(tw.pre(p, av[p], tw.b_of(p, xv), ev), (f32x2)(0.f));
+          if constexpr (EGNN) {
+            const f32x2 ml = m * live;
+            sum[p] += ml;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) vv[p][k] = fma2(ml, pr[k] - ex[0][k], vv[p][k]);
+          } else {
+            sum[p] = fma2(m, live, sum[p]);
+          }
+        }
       },
       [&](int r, bool ok) __attribute__((always_inline)) {
         if (ok) *reinterpret_cast<float4*>(sums + r * pitch + 4 * (lane & 15)) = make_float4(sum[0][0], sum[0][1], sum[1][0], sum[1][1]);
+        if constexpr (EGNN) {
+          float mine = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const f32x2 t = tw.wp[0] * vv[0][k] + tw.wp[1] * vv[1][k];
+            const float v = group_sum(t[0] + t[1]);
+            mine = (lane & 15) == k ? pr[k] + v : mine;
+          }
+          if (ok && (lane & 15) < 3) pos_out[(int64_t)(rb.n0 + row0 + r) * 3 + (lane & 15)] = mine;
+        }
       });
 }
 
 constexpr int kRegionWp = kRegionF + kRegionH;   // row of the update weight in LDS: [x part, zeros up to 4 | aggr part]
-__host__ __device__ inline int64_t region_lds_floats(int cap, bool backward) {
+// (with coordinates a second table of 4 floats per node sits behind the x table; the pass over the sources keeps a
+// third, the gradient arriving at the new coordinates)
+__host__ __device__ inline int64_t region_lds_floats(int cap, bool backward, bool egnn) {
   const int px = island_pitch(kRegionF + kRegionH), pz = island_pitch(kRegionH);
-  return kIslandHeader + (int64_t)kRegionF * cap + kRegionTiles * kTileRows * (px + (backward ? pz : 0)) +
+  return kIslandHeader + (int64_t)kRegionF * cap * (egnn ? 2 : 1) + kRegionTiles * kTileRows * (px + (backward ? pz : 0)) +
          kRegionH * kRegionWp + (backward ? 2 * kRegionH * kRegionH : 0);
+}
+__host__ __device__ inline int64_t region_src_lds_floats(int cap, bool egnn) {
+  return kIslandHeader + (int64_t)kRegionF * cap * (egnn ? 3 : 1) + (int64_t)kRegionWaves * kRegionH * kRegionF;
 }
 
 // W_out [H, F + H] into LDS as float rows of 68 with the x part padded to 4 columns: the tile's rows [x | 0 | aggr]
@@ -1421,7 +1481,7 @@ struct RegionWeights {
   }
 };
 
-template <typename T, int FEW, int FW>
+template <typename T, int FEW, int FW, bool EGNN>
 __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra) {
   extern __shared__ __align__(16) float lds[];
   const IslandLayer& a = ra.l;
@@ -1431,8 +1491,10 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
   const int tile = w >> 1, half = w & 1;
   const int px = island_pitch(kRegionF + H);
   float* xs = lds + kIslandHeader;
-  float* xa = xs + kRegionF * ra.cap + tile * kTileRows * px;
-  float* wl = xs + kRegionF * ra.cap + kRegionTiles * kTileRows * px;
+  float* ps = xs + kRegionF * ra.cap;                       // coordinates of the island's nodes (EGNN)
+  float* tiles = ps + (EGNN ? kRegionF * ra.cap : 0);
+  float* xa = tiles + tile * kTileRows * px;
+  float* wl = tiles + kRegionTiles * kTileRows * px;
   const RegionBlock rb = region_block(a.island_ptr, ra.groups, ra.cap, blockIdx.x);
   if (!rb.live) return;   // whole block
   REGION_PROF(0);
@@ -1442,6 +1504,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
   RegionWeights<T> wo;
   wo.request(a);
   region_table<T>(xs, a, rb);
+  if constexpr (EGNN) region_rows<float>(ps, a.pos, 3, 3, rb);
   wo.store(wl);
   __syncthreads();
   REGION_PROF(1);
@@ -1453,7 +1516,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
     const int r = r0 + (lane >> 2), f = lane & 3;
     xa[r * px + f] = r < tn ? xs[4 * (t0 + r) + f] : 0.f;
   }
-  if (nr > 0) region_sums<T, FEW, FW>(a, tw, xs, rb, t0 + r0, nr, xa + r0 * px + kRegionF, px, lane);
+  if (nr > 0) region_sums<T, FEW, FW, EGNN>(a, tw, xs, ps, rb, t0 + r0, nr, xa + r0 * px + kRegionF, px, lane);
   REGION_PROF(2);
   for (int i = lane; i < (16 - nr) * H; i += 64) xa[(r0 + nr + i / H) * px + kRegionF + (i & (H - 1))] = 0.f;
   if (ra.aggr)   // kept for the backward
@@ -1481,7 +1544,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
   REGION_PROF(5);
 }
 
-template <typename T, int FEW, int FW>
+template <typename T, int FEW, int FW, bool EGNN>
 __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra) {
   extern __shared__ __align__(16) float lds[];
   const IslandLayer& a = ra.l;
@@ -1494,7 +1557,8 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
   int* nrows = reinterpret_cast<int*>(lds);
   int* n0s = nrows + 4;
   float* xs = lds + kIslandHeader;
-  float* tiles = xs + kRegionF * ra.cap;
+  float* ps = xs + kRegionF * ra.cap;                       // coordinates of the island's nodes (EGNN)
+  float* tiles = ps + (EGNN ? kRegionF * ra.cap : 0);
   float* xa = tiles + tile * tile_floats;
   float* ag = xa + kRegionF;
   float* gz = xa + o_gz;
@@ -1552,6 +1616,15 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     }
   }
   region_table<T>(xs, a, rb);
+  float gpv[3] = {0.f, 0.f, 0.f};   // EGNN: lane i holds the gradient arriving at the new coordinates of the wave's row i
+  if constexpr (EGNN) {
+    region_rows<float>(ps, a.pos, 3, 3, rb);
+    if (nr > 0) {
+      const int64_t node = n_first + r0 + ((lane & 15) < nr ? (lane & 15) : nr - 1);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) gpv[q] = a.gpos_out[node * 3 + q];
+    }
+  }
   wo.store(wl);
   __syncthreads();
   REGION_PROF(1);
@@ -1567,11 +1640,22 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
           *reinterpret_cast<const float4*>(ra.aggr + (int64_t)(n_first + r0 + r) * H + c);
     }
   } else if (nr > 0) {
-    region_sums<T, FEW, FW>(a, tw, xs, rb, t0 + r0, nr, ag + r0 * px, px, lane);
+    region_sums<T, FEW, FW, false>(a, tw, xs, ps, rb, t0 + r0, nr, ag + r0 * px, px, lane);
   }
   for (int i = lane; i < (16 - nr) * H; i += 64) ag[(r0 + nr + i / H) * px + (i & (H - 1))] = 0.f;
   __syncthreads();
   REGION_PROF(2);
+  if constexpr (EGNN) {
+    // w_pos . aggr[n] = the sum over the row's edges of w_pos . m_e: what the coordinate gradient needs of the
+    // messages; handed to the pass over the sources, which writes that gradient
+    for (int slot = 0; 4 * slot < nr; ++slot) {
+      const int r = 4 * slot + (lane >> 4);
+      const float4 a4 = *reinterpret_cast<const float4*>(ag + (r0 + (r < nr ? r : 0)) * px + 4 * l);
+      const f32x2 t = tw.wp[0] * f32x2{a4.x, a4.y} + tw.wp[1] * f32x2{a4.z, a4.w};
+      const float v = group_sum(t[0] + t[1]);
+      if (r < nr && l == 0) ra.srow[n_first + r0 + r] = v;
+    }
+  }
   // gW_out's aggr part = gz^T aggr over the rows of the whole block: 2 x 2 output tiles of 32 x 32, the contraction
   // over the block's four row tiles cut in two, so that each of the 8 waves multiplies one output tile over two row
   // tiles; the halves meet in LDS.  (The x part, F columns, is collected by the edge walk below.)
@@ -1618,7 +1702,8 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     for (int f = 0; f < FW; ++f) wx[j >> 1][f][j & 1] = wl[(4 * l + j) * kRegionWp + f];
   __syncthreads();
   REGION_PROF(4);
-  f32x2 gwe[2][FEW], gwa[2][FW], gwx[2][FW];
+  f32x2 gwe[2][FEW], gwa[2][FW], gwx[2][FW], gwp[2];
+  gwp[0] = gwp[1] = (f32x2)(0.f);
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -1635,12 +1720,18 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     }
     REGION_PROF(5);
     f32x2 av[2], gar[2], gzr[2], ga_sum[2];
-    float xr[FW];
+    float xr[FW], pr[3] = {0.f, 0.f, 0.f}, gp[3] = {0.f, 0.f, 0.f};
     float* const gx_part = a.gx ? a.gx_part : nullptr;
-    thin_walk<T, FEW, FW, false>(
-        a.rowptr, a.col, static_cast<const T*>(a.ea), a.Fe, xs, n_first + r0, nr, rb.n0, rb.rn - 1, lane, nullptr,
+    thin_walk<T, FEW, FW, false, EGNN ? 1 : 0>(
+        a.rowptr, a.col, static_cast<const T*>(a.ea), a.Fe, xs, n_first + r0, nr, rb.n0, rb.rn - 1, lane, nullptr, ps, nullptr,
         [&](int r, bool ok) __attribute__((always_inline)) {
           const int rr = r0 + (ok ? r : 0);
+          if constexpr (EGNN) {
+            const float4 p4 = *reinterpret_cast<const float4*>(ps + 4 * (t0 + rr));
+            pr[0] = p4.x; pr[1] = p4.y; pr[2] = p4.z;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) gp[q] = group_value(gpv[q], 4 * (ok ? r : 0));
+          }
           const float4 x4 = *reinterpret_cast<const float4*>(xs + 4 * (t0 + rr));
           const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
@@ -1654,13 +1745,23 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
 #pragma unroll
           for (int p = 0; p < 2; ++p) { av[p] = tw.a_of(p, xr); ga_sum[p] = (f32x2)(0.f); }
         },
-        [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&) __attribute__((always_inline)) {
+        [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4&, const float (&ex)[1][3])
+            __attribute__((always_inline)) {
+          // EGNN: pos'[r] += (pos[r] - pos[s]) sc, sc = w_pos . m; q = d loss / d sc reaches the message through w_pos
+          float q = 0.f;
+          if constexpr (EGNN) {
+            q = gp[0] * (pr[0] - ex[0][0]);
+            q = fmaf(gp[1], pr[1] - ex[0][1], q);
+            q = fmaf(gp[2], pr[2] - ex[0][2], q);
+          }
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             const f32x2 t = tw.pre(p, av[p], tw.b_of(p, xv), ev);
+            const f32x2 up = EGNN ? fma2(tw.wp[p], q, gar[p]) : gar[p];
             f32x2 g;
-            g[0] = t[0] > 0.f ? gar[p][0] : 0.f;
-            g[1] = t[1] > 0.f ? gar[p][1] : 0.f;
+            g[0] = t[0] > 0.f ? up[0] : 0.f;
+            g[1] = t[1] > 0.f ? up[1] : 0.f;
+            if constexpr (EGNN) gwp[p] = fma2(__builtin_elementwise_max(t, (f32x2)(0.f)), q * live, gwp[p]);
             ga_sum[p] = fma2(g, live, ga_sum[p]);
 #pragma unroll
             for (int d = 0; d < FEW; ++d) gwe[p][d] = fma2(g, ev[d], gwe[p][d]);   // (padding carries zero attributes)
@@ -1713,25 +1814,33 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
           slab[H * (a.Fe + F) + c * F + f] = u;
         }
       }
+      if constexpr (EGNN) {
+        const float v = across_groups(gwp[j >> 1][j & 1], lane);
+        if (lane < 16) slab[H * (a.Fe + 2 * F) + c] = v;
+      }
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < H * (a.Fe + 2 * F); e += blockDim.x) {
+  for (int e = threadIdx.x; e < H * (a.Fe + 2 * F + (EGNN ? 1 : 0)); e += blockDim.x) {
     float t = 0.f;
     for (int w2 = 0; w2 < kRegionWaves; ++w2) t += tiles[(w2 >> 1) * tile_floats + o_gz + (w2 & 1) * 16 * pz + e];
     if (e < H * a.Fe) part[o_we + e] = t;
     else if (e < H * (a.Fe + F)) part[o_wn + (e - H * a.Fe)] = t;
-    else {   // gW_out[c][f], f < F
+    else if (e < H * (a.Fe + 2 * F)) {   // gW_out[c][f], f < F
       const int i = e - H * (a.Fe + F);
       part[(i / F) * (F + H) + i % F] = t;
+    } else {   // g w_pos follows gWe
+      part[o_we + H * a.Fe + (e - H * (a.Fe + 2 * F))] = t;
     }
   }
   REGION_PROF(8);
 }
 
 // The pass over the sources: 16 rows per wave.  gB[s] = sum over the edges s -> d of ga[d] where the message was
-// positive; gWn's B half += gB[s] x[s]^T, gx[s] = (what the first pass left) + gB[s] Wn_B.
-template <typename T, int FEW, int FW>
+// positive; gWn's B half += gB[s] x[s]^T, gx[s] = (what the first pass left) + gB[s] Wn_B.  EGNN: the gradient of the
+// coordinates, gpos[s] = gp[s] (1 + w_pos . aggr[s]) - sum over the edges s -> d of gp[d] (w_pos . m_e) with gp the
+// gradient arriving at the new coordinates; the last sum by columns, as in the forward.
+template <typename T, int FEW, int FW, bool EGNN>
 __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLayer ra) {
   extern __shared__ __align__(16) float lds[];
   const IslandLayer& a = ra.l;
@@ -1740,7 +1849,9 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int F = a.F;
   float* xs = lds + kIslandHeader;
-  float* slabs = xs + kRegionF * ra.cap;   // [waves][H * 4]
+  float* ps = xs + kRegionF * ra.cap;       // EGNN: coordinates, and behind them the gradient arriving at the new ones
+  float* gps = ps + kRegionF * ra.cap;
+  float* slabs = xs + kRegionF * ra.cap * (EGNN ? 3 : 1);   // [waves][H * 4]
   const RegionBlock rb = region_block(a.island_ptr, ra.groups, ra.cap, blockIdx.x);
   if (!rb.live) return;
   float* part = a.partial + (int64_t)blockIdx.x * a.partial_stride;
@@ -1749,6 +1860,10 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
   ThinWeights<T, FEW, FW> tw;
   tw.load(a, lane);
   region_table<T>(xs, a, rb);
+  if constexpr (EGNN) {
+    region_rows<float>(ps, a.pos, 3, 3, rb);
+    region_rows<float>(gps, a.gpos_out, 3, 3, rb);
+  }
   __syncthreads();
   REGION_PROF(10);
   const int s0 = rb.base + 16 * w;
@@ -1759,14 +1874,17 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
 #pragma unroll
     for (int f = 0; f < FW; ++f) gwb[p][f] = (f32x2)(0.f);
   if (nr > 0) {
-    f32x2 gb[2], bv[2];
-    float xr[FW];
+    f32x2 gb[2], bv[2], uu[2][3];
+    float xr[FW], pr[3] = {0.f, 0.f, 0.f}, gs[3] = {0.f, 0.f, 0.f}, s_row = 0.f;
+    float sv = 0.f;   // EGNN: lane i holds w_pos . aggr of the wave's row i
+    if constexpr (EGNN) sv = ra.srow[rb.n0 + s0 + ((lane & 15) < nr ? (lane & 15) : nr - 1)];
+    float* const gpos = a.gpos;
     const float* const gx_part = a.gx_part;
     T* const gx = static_cast<T*>(a.gx);
     const int64_t ldgx = a.ldgx;
-    thin_walk<T, FEW, FW, true>(
+    thin_walk<T, FEW, FW, true, EGNN ? 2 : 0>(
         ra.rowptr_t, ra.col_t, static_cast<const T*>(ra.ea_t), a.Fe, xs, rb.n0 + s0, nr, rb.n0, rb.rn - 1, lane,
-        ra.ga + (int64_t)rb.n0 * H,
+        ra.ga + (int64_t)rb.n0 * H, ps, gps,
         [&](int r, bool ok) __attribute__((always_inline)) {
           const float4 x4 = *reinterpret_cast<const float4*>(xs + 4 * (s0 + (ok ? r : 0)));
           const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
@@ -1774,17 +1892,43 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
           for (int f = 0; f < FW; ++f) xr[f] = xv[f];
 #pragma unroll
           for (int p = 0; p < 2; ++p) { bv[p] = tw.b_of(p, xr); gb[p] = (f32x2)(0.f); }
+          if constexpr (EGNN) {
+            const int row = s0 + (ok ? r : 0);
+            const float4 p4 = *reinterpret_cast<const float4*>(ps + 4 * row);
+            const float4 q4 = *reinterpret_cast<const float4*>(gps + 4 * row);
+            pr[0] = p4.x; pr[1] = p4.y; pr[2] = p4.z;
+            gs[0] = q4.x; gs[1] = q4.y; gs[2] = q4.z;
+            s_row = group_value(sv, 4 * (ok ? r : 0));
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+              for (int q = 0; q < 3; ++q) uu[p][q] = (f32x2)(0.f);
+          }
         },
-        [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4& g4) __attribute__((always_inline)) {
+        [&](const float (&xv)[FW], const float (&ev)[FEW], float live, const float4& g4, const float (&ex)[EGNN ? 2 : 1][3])
+            __attribute__((always_inline)) {
           const f32x2 gd[2] = {f32x2{g4.x, g4.y}, f32x2{g4.z, g4.w}};
+          // EGNN: ex[0] = pos[d], ex[1] = gp[d]; q = gp[d] . (pos[d] - pos[s]) as in the first pass
+          float q = 0.f;
+          if constexpr (EGNN) {
+            q = ex[EGNN ? 1 : 0][0] * (ex[0][0] - pr[0]);
+            q = fmaf(ex[EGNN ? 1 : 0][1], ex[0][1] - pr[1], q);
+            q = fmaf(ex[EGNN ? 1 : 0][2], ex[0][2] - pr[2], q);
+          }
 #pragma unroll
           for (int p = 0; p < 2; ++p) {
             // the other end is the edge's destination: A from its row of x, B from this row's - the first pass's bits
             const f32x2 t = tw.pre(p, tw.a_of(p, xv), bv[p], ev);
+            const f32x2 up = EGNN ? fma2(tw.wp[p], q, gd[p]) : gd[p];
             f32x2 g;
-            g[0] = t[0] > 0.f ? gd[p][0] : 0.f;
-            g[1] = t[1] > 0.f ? gd[p][1] : 0.f;
+            g[0] = t[0] > 0.f ? up[0] : 0.f;
+            g[1] = t[1] > 0.f ? up[1] : 0.f;
             gb[p] = fma2(g, live, gb[p]);
+            if constexpr (EGNN) {
+              const f32x2 ml = __builtin_elementwise_max(t, (f32x2)(0.f)) * live;
+#pragma unroll
+              for (int k = 0; k < 3; ++k) uu[p][k] = fma2(ml, ex[EGNN ? 1 : 0][k], uu[p][k]);
+            }
           }
         },
         [&](int r, bool ok) __attribute__((always_inline)) {
@@ -1805,6 +1949,16 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
           if (gx && ok && l < F) {
             const int64_t node = rb.n0 + s0 + r;
             gx[node * ldgx + l] = f32_to_scalar<T>(gx_part[node * F + l] + mine);
+          }
+          if constexpr (EGNN) {
+            float out = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const f32x2 t = tw.wp[0] * uu[0][k] + tw.wp[1] * uu[1][k];
+              const float v = group_sum(t[0] + t[1]);
+              out = l == k ? fmaf(gs[k], 1.f + s_row, -v) : out;
+            }
+            if (ok && l < 3) gpos[(int64_t)(rb.n0 + s0 + r) * 3 + l] = out;
           }
         });
   }
@@ -1829,8 +1983,8 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
 // ascending order, then the sixteen sums of an element are added in ascending order.
 struct RegionReduce {
   const float* partial; int64_t stride; const int32_t* island_ptr; int32_t n_islands, groups, cap;
-  int32_t F, H, Fe;
-  void* g_wout; void* g_wn; void* g_we;
+  int32_t F, H, Fe, egnn;
+  void* g_wout; void* g_wn; void* g_we; void* g_wp;
 };
 
 constexpr int kReduceWays = 16;
@@ -1840,7 +1994,7 @@ __global__ void __launch_bounds__(64 * kReduceWays) k_region_reduce(RegionReduce
   __shared__ float sm[kReduceWays][64];
   const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t n1 = (int64_t)a.H * (a.F + a.H), n2 = (int64_t)2 * a.H * a.F, n3 = (int64_t)a.H * a.Fe;
-  const int64_t total = n1 + n2 + n3;
+  const int64_t total = n1 + n2 + n3 + (a.egnn ? a.H : 0);
   const int64_t e = (int64_t)blockIdx.x * 64 + el;
   float s = 0.f;
   if (e < total) {
@@ -1861,7 +2015,8 @@ __global__ void __launch_bounds__(64 * kReduceWays) k_region_reduce(RegionReduce
     T* dst;
     if (e < n1) dst = a.g_wout ? static_cast<T*>(a.g_wout) + e : nullptr;
     else if (e < n1 + n2) dst = a.g_wn ? static_cast<T*>(a.g_wn) + (e - n1) : nullptr;
-    else dst = a.g_we ? static_cast<T*>(a.g_we) + (e - n1 - n2) : nullptr;
+    else if (e < n1 + n2 + n3) dst = a.g_we ? static_cast<T*>(a.g_we) + (e - n1 - n2) : nullptr;
+    else dst = a.g_wp ? static_cast<T*>(a.g_wp) + (e - n1 - n2 - n3) : nullptr;
     if (dst) *dst = f32_to_scalar<T>(t);
   }
 }
@@ -1982,7 +2137,10 @@ int32_t check_region(const mpnn_island_layer* d, int32_t max_nodes, bool backwar
     return fail(MPNN_E_INVALID, "%s: needs 1 <= F <= %d and 1 <= Fe <= 8", who, kRegionF);
   if (max_nodes < 1 || max_nodes > kRegionMax)
     return fail(MPNN_E_CAPACITY, "%s: islands of up to %d nodes, the limit is %d", who, max_nodes, kRegionMax);
-  if (d->pos) return fail(MPNN_E_INVALID, "%s: the coordinate update is not part of this form", who);
+  const bool egnn = d->pos != nullptr;
+  if (region_lds_floats(max_nodes, true, egnn) * 4 > kIslandLds || region_src_lds_floats(max_nodes, egnn) * 4 > kIslandLds)
+    return fail(MPNN_E_CAPACITY, "%s: islands of up to %d nodes%s do not fit the LDS", who, max_nodes,
+                egnn ? " with coordinates" : "");
   if (d->num_nodes < 0 || d->num_nodes > INT32_MAX || d->n_islands < 0 || d->tail_units != 0 || d->rows != kTileRows)
     return fail(MPNN_E_INVALID, "%s: bad sizes (rows must be %d, tail_units 0)", who, kTileRows);
   if ((int64_t)d->n_islands * ((max_nodes + kRegionRows - 1) / kRegionRows) > INT32_MAX)
@@ -1991,9 +2149,12 @@ int32_t check_region(const mpnn_island_layer* d, int32_t max_nodes, bool backwar
   if (!d->rowptr || !d->col || !d->island_ptr || !d->x || !d->ea || !d->w_nodes || !d->w_edge || !d->w_out || !d->y)
     return fail(MPNN_E_INVALID, "%s: null pointer argument", who);
   if (d->ldx < d->F || d->ldy < d->H) return fail(MPNN_E_INVALID, "%s: leading dimension too small", who);
+  if (egnn && !d->w_pos) return fail(MPNN_E_INVALID, "%s: pos without w_pos", who);
+  if (!backward && egnn && !d->pos_out) return fail(MPNN_E_INVALID, "%s: pos without pos_out", who);
   if (backward) {
     if (!d->gy || !d->partial || d->ldgy < d->H) return fail(MPNN_E_INVALID, "%s: gy / partial missing", who);
     if (d->gx && (!d->gx_part || d->ldgx < d->F)) return fail(MPNN_E_INVALID, "%s: gx needs gx_part and ldgx >= F", who);
+    if (egnn && (!d->gpos_out || !d->gpos)) return fail(MPNN_E_INVALID, "%s: pos without gpos_out / gpos", who);
   }
   return MPNN_OK;
 }
@@ -2006,26 +2167,33 @@ RegionLayer region_args(const mpnn_island_layer* d, int32_t max_nodes) {
   return r;
 }
 
-template <typename T, int FEW, int FW>
+template <typename T, int FEW, int FW, bool EGNN>
 void launch_region(const RegionLayer& r, int kind, int blocks, int64_t lds, hipStream_t stream) {
-  const int id = 64 + ((sizeof(T) == 2) | (FEW == 1) << 1 | (FW == 4) << 2 | kind << 3);
+  const int id = 64 + ((sizeof(T) == 2) | (FEW == 1) << 1 | (FW == 4) << 2 | kind << 3 | EGNN << 5);
   if (kind == 0) {
-    allow_lds(k_region_fwd<T, FEW, FW>, id, lds);
-    k_region_fwd<T, FEW, FW><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+    allow_lds(k_region_fwd<T, FEW, FW, EGNN>, id, lds);
+    k_region_fwd<T, FEW, FW, EGNN><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
   } else if (kind == 1) {
-    allow_lds(k_region_bwd<T, FEW, FW>, id, lds);
-    k_region_bwd<T, FEW, FW><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+    allow_lds(k_region_bwd<T, FEW, FW, EGNN>, id, lds);
+    k_region_bwd<T, FEW, FW, EGNN><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
   } else {
-    allow_lds(k_region_bwd_src<T, FEW, FW>, id, lds);
-    k_region_bwd_src<T, FEW, FW><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+    allow_lds(k_region_bwd_src<T, FEW, FW, EGNN>, id, lds);
+    k_region_bwd_src<T, FEW, FW, EGNN><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
   }
+}
+
+template <typename T, bool EGNN>
+void dispatch_region_e(const RegionLayer& r, int kind, int blocks, int64_t lds, hipStream_t stream) {
+  const bool fe1 = r.l.Fe == 1, f4 = r.l.F == 4;
+  if (fe1) f4 ? launch_region<T, 1, 4, EGNN>(r, kind, blocks, lds, stream) : launch_region<T, 1, 3, EGNN>(r, kind, blocks, lds, stream);
+  else f4 ? launch_region<T, kIslandFeMax, 4, EGNN>(r, kind, blocks, lds, stream)
+          : launch_region<T, kIslandFeMax, 3, EGNN>(r, kind, blocks, lds, stream);
 }
 
 template <typename T>
 void dispatch_region_t(const RegionLayer& r, int kind, int blocks, int64_t lds, hipStream_t stream) {
-  const bool fe1 = r.l.Fe == 1, f4 = r.l.F == 4;
-  if (fe1) f4 ? launch_region<T, 1, 4>(r, kind, blocks, lds, stream) : launch_region<T, 1, 3>(r, kind, blocks, lds, stream);
-  else f4 ? launch_region<T, kIslandFeMax, 4>(r, kind, blocks, lds, stream) : launch_region<T, kIslandFeMax, 3>(r, kind, blocks, lds, stream);
+  if (r.l.pos) dispatch_region_e<T, true>(r, kind, blocks, lds, stream);
+  else dispatch_region_e<T, false>(r, kind, blocks, lds, stream);
 }
 
 void dispatch_region(const RegionLayer& r, int dtype, int kind, int blocks, int64_t lds, hipStream_t stream) {
@@ -2136,14 +2304,16 @@ int32_t mpnn_island_layer_bwd(const mpnn_island_layer* d, mpnn_stream_t stream) 
   return MPNN_OK;
 }
 
-int32_t mpnn_region_layer_fits(int32_t F, int32_t H, int32_t Fe, int32_t max_nodes) {
+int32_t mpnn_region_layer_fits(int32_t F, int32_t H, int32_t Fe, int32_t max_nodes, int32_t egnn) {
   return H == 64 && F >= 1 && F <= kRegionF && Fe >= 1 && Fe <= kIslandFeMax && max_nodes >= 1 && max_nodes <= kRegionMax &&
-         region_lds_floats(max_nodes, true) * 4 <= kIslandLds;
+         region_lds_floats(max_nodes, true, egnn != 0) * 4 <= kIslandLds &&
+         region_src_lds_floats(max_nodes, egnn != 0) * 4 <= kIslandLds;
 }
 
-int64_t mpnn_region_layer_partial_floats(int32_t n_islands, int32_t max_nodes, int32_t F, int32_t H, int32_t Fe) {
-  if (!mpnn_region_layer_fits(F, H, Fe, max_nodes) || n_islands < 0) return -1;
-  return (int64_t)n_islands * ((max_nodes + kRegionRows - 1) / kRegionRows) * island_partial_floats(F, H, Fe, false);
+int64_t mpnn_region_layer_partial_floats(int32_t n_islands, int32_t max_nodes, int32_t F, int32_t H, int32_t Fe,
+                                         int32_t egnn) {
+  if (!mpnn_region_layer_fits(F, H, Fe, max_nodes, egnn) || n_islands < 0) return -1;
+  return (int64_t)n_islands * ((max_nodes + kRegionRows - 1) / kRegionRows) * island_partial_floats(F, H, Fe, egnn != 0);
 }
 
 int32_t mpnn_region_layer_fwd(const mpnn_island_layer* d, int32_t max_nodes, float* aggr, mpnn_stream_t stream) {
@@ -2151,7 +2321,7 @@ int32_t mpnn_region_layer_fwd(const mpnn_island_layer* d, int32_t max_nodes, flo
   if (d->n_islands == 0) return MPNN_OK;
   RegionLayer r = region_args(d, max_nodes);
   r.aggr = aggr;
-  dispatch_region(r, d->dtype, 0, d->n_islands * r.groups, region_lds_floats(r.cap, false) * 4, stream);
+  dispatch_region(r, d->dtype, 0, d->n_islands * r.groups, region_lds_floats(r.cap, false, d->pos != nullptr) * 4, stream);
   MPNN_LAUNCH_CHECK("k_region_fwd");
   return MPNN_OK;
 }
@@ -2162,21 +2332,22 @@ int32_t mpnn_region_layer_bwd(const mpnn_island_layer* d, int32_t max_nodes, con
   if (int32_t rc = check_region(d, max_nodes, true, "mpnn_region_layer_bwd")) return rc;
   if (d->n_islands > 0 && (!rowptr_t || !col_t || !ea_t || !ga))
     return fail(MPNN_E_INVALID, "mpnn_region_layer_bwd: the source-sorted view and the ga scratch are required");
+  const bool egnn = d->pos != nullptr;
   RegionLayer r = region_args(d, max_nodes);
-  r.l.partial_stride = island_partial_floats(d->F, d->H, d->Fe, false);
+  r.l.partial_stride = island_partial_floats(d->F, d->H, d->Fe, egnn);
   r.rowptr_t = rowptr_t; r.col_t = col_t; r.ea_t = ea_t; r.ga = ga;
+  r.srow = ga + d->num_nodes * d->H;   // (read and written with coordinates only)
   r.aggr = const_cast<float*>(aggr);
   const int blocks = d->n_islands * r.groups;
   if (blocks > 0) {
-    dispatch_region(r, d->dtype, 1, blocks, region_lds_floats(r.cap, true) * 4, stream);
+    dispatch_region(r, d->dtype, 1, blocks, region_lds_floats(r.cap, true, egnn) * 4, stream);
     MPNN_LAUNCH_CHECK("k_region_bwd");
-    const int64_t lds = (kIslandHeader + (int64_t)kRegionF * r.cap + (int64_t)kRegionWaves * d->H * kRegionF) * 4;
-    dispatch_region(r, d->dtype, 2, blocks, lds, stream);
+    dispatch_region(r, d->dtype, 2, blocks, region_src_lds_floats(r.cap, egnn) * 4, stream);
     MPNN_LAUNCH_CHECK("k_region_bwd_src");
   }
   RegionReduce rr{d->partial, r.l.partial_stride, d->island_ptr, d->n_islands, r.groups, r.cap, d->F, d->H, d->Fe,
-                  d->g_wout, d->g_wn, d->g_we};
-  const int64_t total = (int64_t)d->H * (d->F + d->H) + (int64_t)2 * d->H * d->F + (int64_t)d->H * d->Fe;
+                  egnn ? 1 : 0, d->g_wout, d->g_wn, d->g_we, d->g_wpos};
+  const int64_t total = (int64_t)d->H * (d->F + d->H) + (int64_t)2 * d->H * d->F + (int64_t)d->H * d->Fe + (egnn ? d->H : 0);
   const int rblocks = (int)((total + 63) / 64);
   if (d->dtype == MPNN_F32) k_region_reduce<float><<<rblocks, 64 * kReduceWays, 0, stream>>>(rr);
   else k_region_reduce<bf16_t><<<rblocks, 64 * kReduceWays, 0, stream>>>(rr);

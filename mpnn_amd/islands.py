@@ -8,7 +8,8 @@ edge-pass launches whose working sets would be a few kilobytes each.
 
 Islands of up to 2048 nodes over rows of x at most 4 wide (the k-NN clouds of experiments/modelnet_exp.py:58 with
 ``data.pos`` as x) take the REGION form of the same idea, mpnn_region_layer_fwd / _bwd: the x of a whole island sits
-in LDS and the projection of an edge's two ends is recomputed from it instead of fetched.
+in LDS and the projection of an edge's two ends is recomputed from it instead of fetched (MPNN layers, and the EGNN
+layer for islands of up to 1024 nodes).
 """
 from __future__ import annotations
 
@@ -66,15 +67,15 @@ def _plan(isl, f: int, h: int, fe: int, egnn: bool, num_nodes: int) -> Plan | No
 
 
 def _region_plan(isl, f: int, h: int, fe: int, egnn: bool, num_nodes: int) -> Plan | None:
-    if egnn or not REGIONS_ENABLED or isl.tail_rows or isl.max_nodes > REGION_MAX_NODES:
+    if not REGIONS_ENABLED or isl.tail_rows or isl.max_nodes > REGION_MAX_NODES:
         return None
-    if not _lib.load().mpnn_region_layer_fits(f, h, fe, isl.max_nodes):
+    if not _lib.load().mpnn_region_layer_fits(f, h, fe, isl.max_nodes, int(egnn)):
         return None
     # every island takes ceil(largest / 128) blocks: not worth it when most of them would find no rows
     groups = (isl.max_nodes + REGION_ROWS - 1) // REGION_ROWS
     if isl.count * groups * REGION_ROWS > 8 * max(num_nodes, 1):
         return None
-    return Plan(ROWS, 0, False, isl.max_nodes)
+    return Plan(ROWS, 0, egnn, isl.max_nodes)
 
 
 def _desc(plan: Plan, graph: MPGraph, x, ea_s, w_nodes, w_edge, w_out, y, pos=None, w_pos=None) -> _lib.IslandLayerDesc:
@@ -115,7 +116,9 @@ def sorted_attr(plan: Plan, graph: MPGraph, edge_attr, dtype):
     return graph.sorted_edge_attr(edge_attr, dtype)
 
 
-def _region_forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, keep: bool):
+def _region_forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, keep: bool, pos=None, w_pos=None):
+    """``saved`` = (x, edge_attr in destination order, w_nodes, w_edge, w_out, the kept sums or None, edge_attr in
+    source order[, pos, w_pos])."""
     n = x.size(0)
     x, _, w_nodes, w_edge, w_out = _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph)
     ea_s, ea_t = sorted_attr(plan, graph, edge_attr, x.dtype)
@@ -123,15 +126,22 @@ def _region_forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w
     y = torch.empty((n, w_out.size(0)), dtype=x.dtype, device=x.device)
     # the sums over incoming edges, kept for the backward (which would otherwise walk the edges once more)
     aggr = torch.empty((n, w_out.size(0)), dtype=torch.float32, device=x.device) if keep else None
-    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y)
+    pos_out = None
+    if plan.egnn:
+        pos, w_pos = pos.contiguous(), w_pos.contiguous()
+        pos_out = torch.empty_like(pos)
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
+    d.pos_out = _lib.ptr(pos_out)
     with _Timed("region_layer_fwd", x.device):
         _lib.check(lib.mpnn_region_layer_fwd(ctypes.byref(d), plan.region_nodes, _lib.ptr(aggr),
                                              _lib.stream_handle(x.device)), "mpnn_region_layer_fwd")
-    return y, None, (x, ea_s, w_nodes, w_edge, w_out, aggr, ea_t)
+    saved = (x, ea_s, w_nodes, w_edge, w_out, aggr, ea_t)
+    return y, pos_out, (saved + (pos, w_pos) if plan.egnn else saved)
 
 
-def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs):
-    x, ea_s, w_nodes, w_edge, w_out, aggr, ea_t = saved
+def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None):
+    x, ea_s, w_nodes, w_edge, w_out, aggr, ea_t = saved[:7]
+    pos, w_pos = saved[7:9] if plan.egnn else (None, None)
     if aggr is not None and (aggr.dtype != torch.float32 or not aggr.is_contiguous()):
         aggr = None                                   # (recomputed)
     need_x, need_wn, need_we, need_wout = needs
@@ -140,34 +150,40 @@ def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs):
     n, f = x.shape
     h = w_out.size(0)
     gy = gy if gy.is_contiguous() else gy.contiguous()
-    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y)
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
     d.gy, d.ldgy = _lib.ptr(gy), gy.stride(0)
     gx = torch.empty((n, f), dtype=dt, device=dev) if need_x else None
     g_wn = torch.empty_like(w_nodes) if need_wn else None
     g_we = torch.empty_like(w_edge) if need_we else None
     g_wout = torch.empty_like(w_out) if need_wout else None
+    gpos = g_wpos = None
+    if plan.egnn:
+        gpos_out = gpos_out.contiguous().float()
+        gpos = torch.empty_like(pos)
+        g_wpos = torch.empty_like(w_pos)
+        d.gpos_out, d.gpos, d.g_wpos = _lib.ptr(gpos_out), _lib.ptr(gpos), _lib.ptr(g_wpos)
     d.gx, d.ldgx = _lib.ptr(gx), (gx.stride(0) if gx is not None else 0)
     d.g_wn, d.g_we, d.g_wout = _lib.ptr(g_wn), _lib.ptr(g_we), _lib.ptr(g_wout)
-    floats = lib.mpnn_region_layer_partial_floats(graph.islands.count, plan.region_nodes, f, h, ea_s.size(1))
+    floats = lib.mpnn_region_layer_partial_floats(graph.islands.count, plan.region_nodes, f, h, ea_s.size(1), int(plan.egnn))
     if floats < 0:
         raise _lib.MpnnError("mpnn_region_layer_partial_floats rejected the layer's shape")
     d.partial = _lib.ptr(graph.scratch("region_partial", (max(floats, 1),), torch.float32, dev))
     if need_x:
         d.gx_part = _lib.ptr(graph.scratch("region_gx", (n, f), torch.float32, dev))
-    ga = graph.scratch("region_ga", (n, h), torch.float32, dev)
+    ga = graph.scratch("region_ga", (n * h + n,), torch.float32, dev)     # (+ one float per node with coordinates)
     src = graph.by_src
     with _Timed("region_layer_bwd", dev):
         _lib.check(lib.mpnn_region_layer_bwd(ctypes.byref(d), plan.region_nodes, _lib.ptr(src.rowptr), _lib.ptr(src.col),
                                              _lib.ptr(ea_t), _lib.ptr(aggr), _lib.ptr(ga), _lib.stream_handle(dev)),
                    "mpnn_region_layer_bwd")
-    return gx, g_wn, g_we, g_wout, None, None
+    return gx, g_wn, g_we, g_wout, gpos, g_wpos
 
 
 def forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, pos=None, w_pos=None, keep=True):
     """y (and pos' for the EGNN form) of one layer.  Returns (y, pos_out | None, saved) where ``saved`` are the
     contiguous tensors the backward needs (``keep`` false: no backward will follow)."""
     if plan.region_nodes:
-        return _region_forward(plan, graph, x, edge_attr, w_nodes, w_edge, w_out, keep)
+        return _region_forward(plan, graph, x, edge_attr, w_nodes, w_edge, w_out, keep, pos, w_pos)
     x, ea_s, w_nodes, w_edge, w_out = _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph)
     lib = _lib.load()
     y = torch.empty((x.size(0), w_out.size(0)), dtype=x.dtype, device=x.device)
@@ -187,7 +203,7 @@ def backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None):
     """Gradients of one layer.  ``needs`` = (x, w_nodes, w_edge, w_out) wanted; returns (gx, g_wn, g_we, g_wout,
     gpos, g_wpos), None where not wanted (gpos / g_wpos only for the EGNN form)."""
     if plan.region_nodes:
-        return _region_backward(plan, graph, gy, y, saved, needs)
+        return _region_backward(plan, graph, gy, y, saved, needs, gpos_out)
     x, ea_s, w_nodes, w_edge, w_out, pos, w_pos = saved
     need_x, need_wn, need_we, need_wout = needs
     lib = _lib.load()

@@ -124,6 +124,96 @@ def test_region_layer_outputs_and_every_gradient(mode, dtype, f, fe, max_nodes):
     assert all(torch.equal(grads3[k], grads[k]) for k in grads)
 
 
+EGNN_CASES = [
+    pytest.param(torch.float32, 3, 1, 300, id="egnn-f32-F3-Fe1"),
+    pytest.param(torch.float32, 4, 4, 523, id="egnn-f32-F4-Fe4"),
+    pytest.param(torch.float32, 2, 3, 1024, id="egnn-f32-F2-Fe3-1024"),
+    pytest.param(torch.bfloat16, 3, 1, 300, id="egnn-bf16-F3-Fe1"),
+]
+
+
+@pytest.mark.parametrize("dtype,f,fe,max_nodes", EGNN_CASES)
+def test_region_egnn_layer_outputs_and_every_gradient(dtype, f, fe, max_nodes):
+    """The EGNN layer (messages as above plus pos'[n] = pos[n] + sum (pos[n] - pos[src]) (w_pos . m)) on the same
+    kernels: y, pos' and the gradients of x, pos and all four weights against the float64 oracle."""
+    from mpnn_amd import EGNNLayer, islands
+    from mpnn_amd.graph import graph_for
+    d = clouds(3 * f + fe + max_nodes, 3 if max_nodes > 1000 else 10, max_nodes, f, fe)
+    n, h = d["n"], 64
+    gen = torch.Generator().manual_seed(11 + f)
+    pos = torch.randn(n, 3, generator=gen)
+    x, ea, ei = d["x"].to(dtype), d["edge_attr"].to(dtype), d["edge_index"]
+    torch.manual_seed(5 + f)
+    layer = EGNNLayer(f, fe, h)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.copy_(p.to(dtype).float())
+    params = {k: v.detach().clone().double().requires_grad_(True) for k, v in layer.state_dict().items()}
+    r, rp = torch.randn(n, h, generator=gen), torch.randn(n, 3, generator=gen)
+    xc, pc = x.double().requires_grad_(True), pos.double().requires_grad_(True)
+    want, want_pos = O.egnn_full_layer(xc, pc, ei, ea.double(), params["fused_linear.weight"], params["linear_3.weight"],
+                                       params["linear_out.weight"], params["coord_linear.weight"])
+    ((want * r.double()).sum() + (want_pos * rp.double()).sum()).backward()
+
+    def run():
+        lay = layer.to(DEV).to(dtype)
+        for p in lay.parameters():
+            p.grad = None
+        xg, pg = x.to(DEV).clone().requires_grad_(True), pos.to(DEV).clone().requires_grad_(True)
+        y, pos_out = lay(xg, pg, ei.to(DEV), ea.to(DEV))
+        ((y.float() * r.to(DEV)).sum() + (pos_out * rp.to(DEV)).sum()).backward()
+        return y, pos_out, xg.grad, pg.grad, {k: p.grad.clone() for k, p in lay.named_parameters()}
+
+    y, pos_out, gx, gpos, grads = run()
+    graph = graph_for(ei.to(DEV), n)
+    plan = islands.plan_for(graph, f, h, fe, True)
+    assert plan is not None and plan.region_nodes == max_nodes and plan.egnn, "the region kernels did not take this layer"
+    rtol, kink = RTOL[dtype], KINK[dtype]
+    assert y.dtype == dtype and pos_out.dtype == torch.float32
+    assert_close(y.float(), want, rtol, what="y")
+    assert_close(pos_out, want_pos, rtol, what="pos'")
+    assert_close(gx.float(), xc.grad, rtol, atol_scale=4.0, what="grad x", kink_frac=kink)
+    assert_close(gpos, pc.grad, rtol, atol_scale=4.0, what="grad pos", kink_frac=kink)
+    for k, g in grads.items():
+        assert g.shape == params[k].shape
+        assert_close(g.float(), params[k].grad, rtol, atol_scale=4.0, what=f"grad {k}", kink_frac=kink)
+    y2, pos2, gx2, gpos2, grads2 = run()
+    assert torch.equal(y2, y) and torch.equal(pos2, pos_out) and torch.equal(gx2, gx) and torch.equal(gpos2, gpos)
+    assert all(torch.equal(grads2[k], grads[k]) for k in grads)
+
+
+def test_knn_clouds_egnn_layer_agrees_with_the_general_path(monkeypatch):
+    """BASELINE's point-cloud EGNN shape, smaller: k-NN clouds, x = pos, one edge feature."""
+    from mpnn_amd import EGNNLayer, islands, synth
+    from mpnn_amd.graph import clear_cache, graph_for
+    d = synth.modelnet(DEV, 5, 3)
+    x, ei, ea = d["x"].clone(), d["edge_index"], d["edge_attr"]
+    pos = d["pos"].float().clone()
+    n = x.size(0)
+    torch.manual_seed(0)
+    layer = EGNNLayer(3, 1, 64).to(DEV)
+    r, rp = torch.randn(n, 64, device=DEV), torch.randn(n, 3, device=DEV)
+
+    def run():
+        for p in layer.parameters():
+            p.grad = None
+        xg, pg = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        y, po = layer(xg, pg, ei, ea)
+        ((y * r).sum() + (po * rp).sum()).backward()
+        return [y, po, xg.grad, pg.grad] + [p.grad.clone() for p in layer.parameters()]
+
+    got = run()
+    plan = islands.plan_for(graph_for(ei, n), 3, 64, 1, True)
+    assert plan is not None and plan.region_nodes == 1024 and plan.egnn
+    monkeypatch.setattr(islands, "REGIONS_ENABLED", False)
+    clear_cache()
+    assert islands.plan_for(graph_for(ei, n), 3, 64, 1, True) is None
+    want = run()
+    for i, (g, w) in enumerate(zip(got, want)):
+        # (two float32 evaluations: a relu decision at zero may differ and moves the two end rows' gradients)
+        assert_close(g, w.double(), 1e-5, atol_scale=1.0 if i < 2 else 4.0, what=f"output {i}", kink_frac=2e-4 if i in (2, 3) else 1e-5)
+
+
 def test_knn_clouds_take_the_region_kernels_and_agree_with_the_general_path(monkeypatch):
     """The benchmark's own shape, smaller: k-NN clouds built by the library, x = pos, one edge feature."""
     from mpnn_amd import MPNNLayerSum, islands, synth
@@ -192,12 +282,16 @@ def test_region_entry_points_reject_what_they_do_not_take():
     import ctypes
     from mpnn_amd import _lib
     lib = _lib.load()
-    assert lib.mpnn_region_layer_fits(3, 64, 1, 1024) == 1
-    assert lib.mpnn_region_layer_fits(5, 64, 1, 1024) == 0          # x too wide
-    assert lib.mpnn_region_layer_fits(3, 128, 1, 1024) == 0         # H
-    assert lib.mpnn_region_layer_fits(3, 64, 1, 2049) == 0          # island too large
-    assert lib.mpnn_region_layer_partial_floats(4, 1024, 3, 64, 1) > 0
-    assert lib.mpnn_region_layer_partial_floats(4, 4096, 3, 64, 1) == -1
+    assert lib.mpnn_region_layer_fits(3, 64, 1, 1024, 0) == 1
+    assert lib.mpnn_region_layer_fits(3, 64, 1, 2048, 0) == 1
+    assert lib.mpnn_region_layer_fits(3, 64, 1, 1024, 1) == 1
+    assert lib.mpnn_region_layer_fits(3, 64, 1, 2048, 1) == 0       # with coordinates: three tables in the LDS
+    assert lib.mpnn_region_layer_fits(5, 64, 1, 1024, 0) == 0       # x too wide
+    assert lib.mpnn_region_layer_fits(3, 128, 1, 1024, 0) == 0      # H
+    assert lib.mpnn_region_layer_fits(3, 64, 1, 2049, 0) == 0       # island too large
+    assert lib.mpnn_region_layer_partial_floats(4, 1024, 3, 64, 1, 0) > 0
+    assert lib.mpnn_region_layer_partial_floats(4, 1024, 3, 64, 1, 1) > lib.mpnn_region_layer_partial_floats(4, 1024, 3, 64, 1, 0)
+    assert lib.mpnn_region_layer_partial_floats(4, 4096, 3, 64, 1, 0) == -1
     d = _lib.IslandLayerDesc()
     d.F, d.H, d.Fe, d.dtype, d.rows, d.n_islands, d.num_nodes = 3, 64, 1, 0, 32, 1, 64
     assert lib.mpnn_region_layer_fwd(ctypes.byref(d), 64, None, None) != 0     # null pointers
