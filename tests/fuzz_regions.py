@@ -1,5 +1,6 @@
 """Randomised sweep of the point-cloud whole-layer kernels (mpnn_region_layer_fwd / _bwd) against the float64 oracle
-with flip-aware gradient bars (oracle/flip_bounds.py).  Run by hand on the GPU: python tests/fuzz_regions.py [seed] [cases]
+with flip-aware gradient bars (oracle/flip_bounds.py), MPNN layers (sum and cat form) and the EGNN layer.  Run by hand on
+the GPU: python tests/fuzz_regions.py [seed] [cases]
 
 Every case draws island sizes around the kernels' boundaries (16-row half tiles, 32-row tiles, 128-row blocks), rows
 with no edge, rows with more than 32 in-edges or out-edges (several staged pieces per row, groups of a wave with
@@ -13,7 +14,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from mpnn_amd import MPNNLayerCat, MPNNLayerSum, islands          # noqa: E402
+from mpnn_amd import EGNNLayer, MPNNLayerCat, MPNNLayerSum, islands  # noqa: E402
 from mpnn_amd.graph import clear_cache, graph_for                  # noqa: E402
 from oracle import flip_bounds as FB                               # noqa: E402
 
@@ -25,7 +26,8 @@ R = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
 taken = 0
 for c in range(cases):
     f, fe = R(1, 4), [1, 1, R(2, 8)][R(0, 2)]
-    mode = "sum" if R(0, 1) else "cat"
+    egnn = R(0, 2) == 0
+    mode = "sum" if egnn or R(0, 1) else "cat"
     dtype = torch.bfloat16 if R(0, 3) == 0 else torch.float32
     count = R(1, 10)
     edge = [16, 32, 128][R(0, 2)]
@@ -33,6 +35,8 @@ for c in range(cases):
     sizes[0] = max(sizes)
     if R(0, 4) == 0:
         sizes[0] = R(1500, 2048)
+    if egnn:                                                      # with coordinates: islands of up to 1024 nodes
+        sizes = [min(v, 1024) for v in sizes]
     src, dst, off = [], [], 0
     for nn in sizes:
         e = R(nn, 8 * nn)
@@ -54,8 +58,9 @@ for c in range(cases):
     x = torch.randn(n, f, generator=g).to(dtype)
     ea = torch.randn(ei.size(1), fe, generator=g).to(dtype)
     r = torch.randn(n, h, generator=g)
+    pos, rp = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
     torch.manual_seed(1000 * seed + c)
-    layer = (MPNNLayerSum if mode == "sum" else MPNNLayerCat)(f, fe, h)
+    layer = EGNNLayer(f, fe, h) if egnn else (MPNNLayerSum if mode == "sum" else MPNNLayerCat)(f, fe, h)
     with torch.no_grad():
         for p in layer.parameters():
             p.copy_(p.to(dtype).float())
@@ -64,16 +69,25 @@ for c in range(cases):
         wn, we, wo = sd["fused_linear.weight"], sd["linear_3.weight"], sd["linear_out.weight"]
     else:
         (wn, we), wo = FB.cat_to_sum_weights(sd["linear.weight"], f), sd["linear_out.weight"]
-    trace = FB.LayerTrace(x.double(), ei, ea.double(), wn, we, wo, FB.DELTA[dtype])
-    want = trace.backward(r)
+    if egnn:
+        trace = FB.LayerTrace(x.double(), ei, ea.double(), wn, we, wo, FB.DELTA[dtype], pos, sd["coord_linear.weight"])
+        want = trace.backward(r, gpos=rp)
+    else:
+        trace = FB.LayerTrace(x.double(), ei, ea.double(), wn, we, wo, FB.DELTA[dtype])
+        want = trace.backward(r)
     clear_cache()
     layer = layer.to(DEV).to(dtype)
     xg = x.to(DEV).requires_grad_(True)
+    pg = pos.to(DEV).requires_grad_(True)
     eig = ei.to(DEV)
-    y = layer(xg, eig, ea.to(DEV))
-    (y.float() * r.to(DEV)).sum().backward()
+    if egnn:
+        y, pos_out = layer(xg, pg, eig, ea.to(DEV))
+        ((y.float() * r.to(DEV)).sum() + (pos_out * rp.to(DEV)).sum()).backward()
+    else:
+        y = layer(xg, eig, ea.to(DEV))
+        (y.float() * r.to(DEV)).sum().backward()
     graph = graph_for(eig, n)
-    plan = islands.plan_for(graph, f, h, fe, False)
+    plan = islands.plan_for(graph, f, h, fe, egnn)
     used = plan is not None and plan.region_nodes > 0
     taken += used
     grads = {k: p.grad for k, p in layer.named_parameters()}
@@ -85,8 +99,11 @@ for c in range(cases):
     else:
         lin = tuple(FB.cat_grad_from_sum(want["w_nodes"][i], want["w_edge"][i], h) for i in range(3))
         entries.append(("linear", grads["linear.weight"], lin, 4.0))
+    if egnn:
+        entries += [("pos'", pos_out, (trace.pos_out,) + none), ("pos", pg.grad, want["pos"], 4.0),
+                    ("w_pos", grads["coord_linear.weight"].reshape(-1), want["w_pos"], 4.0)]
     rep = FB.report(entries, rtol)
-    tag = (f"case {c}: {mode} {str(dtype)[6:]} F={f} Fe={fe} islands={len(sizes)} largest={max(sizes)} nodes={n} "
+    tag = (f"case {c}: {'egnn' if egnn else mode} {str(dtype)[6:]} F={f} Fe={fe} islands={len(sizes)} largest={max(sizes)} nodes={n} "
            f"edges={ei.size(1)} region={used}")
     if not rep["ok"]:
         print("FAILED", tag, "::", rep["worst"])
