@@ -1,5 +1,7 @@
-set -e
-timeout -k 10 500 python -u -m pytest tests/test_gpu_regions.py -x -q --timeout 120 --timeout-method thread 2>&1 | tail -15
-for spec in "--workload modelnet" "--workload modelnet --layer egnn"; do
-echo "== $spec graph"; timeout -k 10 120 python bench.py $spec --steps 300 --warmup 30 --hip-graph --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['verified']['ok'])"
-done
+set -o pipefail
+O=$GRAFT_REPO_ROOT/gpurun_out/profiles
+mkdir -p $O
+cd $GRAFT_REPO_ROOT
+bash tools/bench_all.sh r03 > gpurun_out/bench_all.log 2>&1 || { echo bench_all failed; tail -5 gpurun_out/bench_all.log; exit 1; }
+( MPNN_AMD_LIB=$GRAFT_REPO_ROOT/tools/libmpnn_prof.so timeout -k 10 120 python3 tools/region_prof.py 32 && echo "--- EGNN layer" && MPNN_AMD_LIB=$GRAFT_REPO_ROOT/tools/libmpnn_prof.so timeout -k 10 120 python3 tools/region_prof.py 32 egnn ) 2>&1 | grep -v amdgpu.ids > $O/r03_region_phases.txt || exit 1
+echo done
