@@ -40,14 +40,16 @@ def forward_impl(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph, want: boo
     """The forward sequence of library calls.  Returns (y, ab, aggr, cnt, maskbits, ea); cnt = (byte counts, exact
     counts of the long rows or None) and maskbits are None when ``want`` (a backward will follow) is false, maskbits
     also when no mask layout exists.  ``ea`` is the sorted layout of edge_attr the backward reads: transpose order
-    on the general path, destination order when the graph's islands let the layer run as one launch."""
+    on the general path, destination order when the graph's islands let the layer run as one launch (the pair of
+    both orders for the point-cloud form, see islands.sorted_attr)."""
     bf = x.dtype == torch.bfloat16
     x = x if x.is_contiguous() else x.contiguous()
     f = x.size(1)
     h = w_out.size(0)
     plan = islands.plan_for(graph, f, h, edge_attr.size(1), False)
     if plan is not None:
-        # one launch for the whole layer; its backward recomputes the intermediates, so the slots that carry them
+        # one launch for the whole layer; its backward recomputes the intermediates (the point-cloud form keeps its
+        # sums over edges), so the slots that carry them
         # on the general path hold unwritten tensors of the same shapes
         y, _, saved = islands.forward(plan, graph, x, edge_attr, w_nodes, w_edge, w_out, keep=want)
         n = x.size(0)
@@ -157,7 +159,7 @@ class _LayerFn(torch.autograd.Function):
         want = any(ctx.needs_input_grad[i] for i in (0, 2, 3, 4))
         x = x if x.is_contiguous() else x.contiguous()
         ctx.plan = islands.plan_for(graph, x.size(1), w_out.size(0), edge_attr.size(1), False)
-        if ctx.plan is not None:   # the whole layer in one launch; the backward recomputes the intermediates
+        if ctx.plan is not None:   # the whole layer in one launch; `saved` is all its backward needs
             y, _, saved = islands.forward(ctx.plan, graph, x, edge_attr, w_nodes, w_edge, w_out, keep=want)
             if want:
                 ctx.save_for_backward(y, *saved)
@@ -201,7 +203,7 @@ class _EgnnLayerFn(torch.autograd.Function):
         f, h = x.size(1), w_out.size(0)
         ctx.plan = islands.plan_for(graph, f, h, edge_attr.size(1), True)
         ctx.w_pos_shape = w_pos.shape
-        if ctx.plan is not None:   # the whole layer in one launch; the backward recomputes the intermediates
+        if ctx.plan is not None:   # the whole layer in one launch; `saved` is all its backward needs
             y, pos_out, saved = islands.forward(ctx.plan, graph, x, edge_attr, w_nodes, w_edge, w_out, pos, w_pos.reshape(-1))
             ctx.save_for_backward(y, *saved)
             ctx.graph = graph
