@@ -1129,6 +1129,8 @@ struct RegionLayer {
   float* ga;        // [N, H] gradient arriving at the sums
   float* aggr;      // [N, H] the sums: written by the forward, read by the backward (null: not kept / recomputed)
   float* srow;      // [N] EGNN backward: w_pos . aggr[n], from the first pass to the second
+  int32_t wnb;      // backward without gx (and without coordinates): the first pass also collects the B half of gWn,
+                    // and the pass over the sources is not launched
 };
 
 struct RegionBlock { int n0, rn, base; bool live; };   // island [n0, n0 + rn), the block's rows start at local row base
@@ -1544,7 +1546,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_fwd(RegionLayer ra
   REGION_PROF(5);
 }
 
-template <typename T, int FEW, int FW, bool EGNN>
+template <typename T, int FEW, int FW, bool EGNN, bool WNB>
 __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra) {
   extern __shared__ __align__(16) float lds[];
   const IslandLayer& a = ra.l;
@@ -1702,15 +1704,16 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     for (int f = 0; f < FW; ++f) wx[j >> 1][f][j & 1] = wl[(4 * l + j) * kRegionWp + f];
   __syncthreads();
   REGION_PROF(4);
-  f32x2 gwe[2][FEW], gwa[2][FW], gwx[2][FW], gwp[2];
+  f32x2 gwe[2][FEW], gwa[2][FW], gwx[2][FW], gwb[2][FW], gwp[2];
   gwp[0] = gwp[1] = (f32x2)(0.f);
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
 #pragma unroll
     for (int d = 0; d < FEW; ++d) gwe[p][d] = (f32x2)(0.f);
 #pragma unroll
-    for (int f = 0; f < FW; ++f) gwa[p][f] = gwx[p][f] = (f32x2)(0.f);
+    for (int f = 0; f < FW; ++f) gwa[p][f] = gwx[p][f] = gwb[p][f] = (f32x2)(0.f);
   }
+  constexpr bool wnb = WNB && !EGNN;   // no gx wanted: gB[s] itself is not needed, only gB^T x
   if (nr > 0) {
     // ga of this wave's rows for the pass over the sources
     for (int i = lane; i < nr * (H / 4); i += 64) {
@@ -1763,6 +1766,11 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
             g[1] = t[1] > 0.f ? up[1] : 0.f;
             if constexpr (EGNN) gwp[p] = fma2(__builtin_elementwise_max(t, (f32x2)(0.f)), q * live, gwp[p]);
             ga_sum[p] = fma2(g, live, ga_sum[p]);
+            if constexpr (wnb) {   // the edge's share of gWn's B half, g x[src]^T, taken here instead of in a pass by sources
+              const f32x2 gl = g * live;
+#pragma unroll
+              for (int f = 0; f < FW; ++f) gwb[p][f] = fma2(gl, xv[f], gwb[p][f]);
+            }
 #pragma unroll
             for (int d = 0; d < FEW; ++d) gwe[p][d] = fma2(g, ev[d], gwe[p][d]);   // (padding carries zero attributes)
           }
@@ -1817,11 +1825,17 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
       if constexpr (EGNN) {
         const float v = across_groups(gwp[j >> 1][j & 1], lane);
         if (lane < 16) slab[H * (a.Fe + 2 * F) + c] = v;
+      } else if constexpr (wnb) {
+#pragma unroll
+        for (int f = 0; f < FW; ++f) {
+          const float v = across_groups(gwb[j >> 1][f][j & 1], lane);
+          if (lane < 16 && f < F) slab[H * (a.Fe + 2 * F) + c * F + f] = v;
+        }
       }
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < H * (a.Fe + 2 * F + (EGNN ? 1 : 0)); e += blockDim.x) {
+  for (int e = threadIdx.x; e < H * (a.Fe + 2 * F + (EGNN ? 1 : (wnb ? F : 0))); e += blockDim.x) {
     float t = 0.f;
     for (int w2 = 0; w2 < kRegionWaves; ++w2) t += tiles[(w2 >> 1) * tile_floats + o_gz + (w2 & 1) * 16 * pz + e];
     if (e < H * a.Fe) part[o_we + e] = t;
@@ -1829,8 +1843,10 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     else if (e < H * (a.Fe + 2 * F)) {   // gW_out[c][f], f < F
       const int i = e - H * (a.Fe + F);
       part[(i / F) * (F + H) + i % F] = t;
-    } else {   // g w_pos follows gWe
+    } else if (EGNN) {   // g w_pos follows gWe
       part[o_we + H * a.Fe + (e - H * (a.Fe + 2 * F))] = t;
+    } else {   // the B half of gWn follows the A half
+      part[o_wn + H * F + (e - H * (a.Fe + 2 * F))] = t;
     }
   }
   REGION_PROF(8);
@@ -2173,9 +2189,14 @@ void launch_region(const RegionLayer& r, int kind, int blocks, int64_t lds, hipS
   if (kind == 0) {
     allow_lds(k_region_fwd<T, FEW, FW, EGNN>, id, lds);
     k_region_fwd<T, FEW, FW, EGNN><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+  } else if (kind == 1 && r.wnb) {
+    if constexpr (!EGNN) {
+      allow_lds(k_region_bwd<T, FEW, FW, false, true>, id | 24, lds);   // (kind 3 in the id)
+      k_region_bwd<T, FEW, FW, false, true><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+    }
   } else if (kind == 1) {
-    allow_lds(k_region_bwd<T, FEW, FW, EGNN>, id, lds);
-    k_region_bwd<T, FEW, FW, EGNN><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
+    allow_lds(k_region_bwd<T, FEW, FW, EGNN, false>, id, lds);
+    k_region_bwd<T, FEW, FW, EGNN, false><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
   } else {
     allow_lds(k_region_bwd_src<T, FEW, FW, EGNN>, id, lds);
     k_region_bwd_src<T, FEW, FW, EGNN><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
@@ -2339,11 +2360,16 @@ int32_t mpnn_region_layer_bwd(const mpnn_island_layer* d, int32_t max_nodes, con
   r.srow = ga + d->num_nodes * d->H;   // (read and written with coordinates only)
   r.aggr = const_cast<float*>(aggr);
   const int blocks = d->n_islands * r.groups;
+  // Without gx (a model's first layer) and without coordinates nothing needs gB[s] itself: the first pass then takes
+  // gB^T x per edge and the pass over the sources is skipped (when the wave's share fits its slab: Fe + 3 F <= 17).
+  r.wnb = !egnn && !d->gx && d->Fe + 3 * d->F <= 17;
   if (blocks > 0) {
     dispatch_region(r, d->dtype, 1, blocks, region_lds_floats(r.cap, true, egnn) * 4, stream);
     MPNN_LAUNCH_CHECK("k_region_bwd");
-    dispatch_region(r, d->dtype, 2, blocks, region_src_lds_floats(r.cap, egnn) * 4, stream);
-    MPNN_LAUNCH_CHECK("k_region_bwd_src");
+    if (!r.wnb) {
+      dispatch_region(r, d->dtype, 2, blocks, region_src_lds_floats(r.cap, egnn) * 4, stream);
+      MPNN_LAUNCH_CHECK("k_region_bwd_src");
+    }
   }
   RegionReduce rr{d->partial, r.l.partial_stride, d->island_ptr, d->n_islands, r.groups, r.cap, d->F, d->H, d->Fe,
                   egnn ? 1 : 0, d->g_wout, d->g_wn, d->g_we, d->g_wpos};
