@@ -577,8 +577,9 @@ int32_t mpnn_island_layer_bwd(const mpnn_island_layer* desc, mpnn_stream_t strea
  *   ga        float [N, H] scratch, N more floats behind it when pos is given
  *   aggr      float [N, H]: the sums over incoming edges, written by the forward when given and handed to the
  *             backward, which otherwise (NULL) walks the edges once more to recompute them
- * Without gx (a model's first layer) and without coordinates the backward is two launches: the pass over the source
- * rows is not needed, the destination pass collects the whole of g_wn (when Fe + 3 F <= 17).
+ * Without gx and without gpos (both NULL: a model's first layer, whose inputs want no gradient) the backward is two
+ * launches: the pass over the source rows is not needed, the destination pass collects the whole of g_wn (when
+ * Fe + 3 F (+ 1 with coordinates) <= 17).  gpos alone may be NULL as well (it is then not written).
  * ------------------------------------------------------------------------- */
 int32_t mpnn_region_layer_fits(int32_t F, int32_t H, int32_t Fe, int32_t max_nodes, int32_t egnn);
 int64_t mpnn_region_layer_partial_floats(int32_t n_islands, int32_t max_nodes, int32_t F, int32_t H, int32_t Fe,

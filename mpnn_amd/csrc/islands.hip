@@ -1647,7 +1647,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
   for (int i = lane; i < (16 - nr) * H; i += 64) ag[(r0 + nr + i / H) * px + (i & (H - 1))] = 0.f;
   __syncthreads();
   REGION_PROF(2);
-  if constexpr (EGNN) {
+  if constexpr (EGNN && !WNB) {
     // w_pos . aggr[n] = the sum over the row's edges of w_pos . m_e: what the coordinate gradient needs of the
     // messages; handed to the pass over the sources, which writes that gradient
     for (int slot = 0; 4 * slot < nr; ++slot) {
@@ -1713,7 +1713,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
 #pragma unroll
     for (int f = 0; f < FW; ++f) gwa[p][f] = gwx[p][f] = gwb[p][f] = (f32x2)(0.f);
   }
-  constexpr bool wnb = WNB && !EGNN;   // no gx wanted: gB[s] itself is not needed, only gB^T x
+  constexpr bool wnb = WNB;   // no gx (and no gradient of the coordinates) wanted: gB[s] itself is not needed, only gB^T x
   if (nr > 0) {
     // ga of this wave's rows for the pass over the sources
     for (int i = lane; i < nr * (H / 4); i += 64) {
@@ -1825,17 +1825,18 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
       if constexpr (EGNN) {
         const float v = across_groups(gwp[j >> 1][j & 1], lane);
         if (lane < 16) slab[H * (a.Fe + 2 * F) + c] = v;
-      } else if constexpr (wnb) {
+      }
+      if constexpr (wnb) {
 #pragma unroll
         for (int f = 0; f < FW; ++f) {
           const float v = across_groups(gwb[j >> 1][f][j & 1], lane);
-          if (lane < 16 && f < F) slab[H * (a.Fe + 2 * F) + c * F + f] = v;
+          if (lane < 16 && f < F) slab[H * (a.Fe + 2 * F + (EGNN ? 1 : 0)) + c * F + f] = v;
         }
       }
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < H * (a.Fe + 2 * F + (EGNN ? 1 : (wnb ? F : 0))); e += blockDim.x) {
+  for (int e = threadIdx.x; e < H * (a.Fe + 2 * F + (EGNN ? 1 : 0) + (wnb ? F : 0)); e += blockDim.x) {
     float t = 0.f;
     for (int w2 = 0; w2 < kRegionWaves; ++w2) t += tiles[(w2 >> 1) * tile_floats + o_gz + (w2 & 1) * 16 * pz + e];
     if (e < H * a.Fe) part[o_we + e] = t;
@@ -1843,10 +1844,10 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd(RegionLayer ra
     else if (e < H * (a.Fe + 2 * F)) {   // gW_out[c][f], f < F
       const int i = e - H * (a.Fe + F);
       part[(i / F) * (F + H) + i % F] = t;
-    } else if (EGNN) {   // g w_pos follows gWe
+    } else if (EGNN && e < H * (a.Fe + 2 * F + 1)) {   // g w_pos follows gWe
       part[o_we + H * a.Fe + (e - H * (a.Fe + 2 * F))] = t;
     } else {   // the B half of gWn follows the A half
-      part[o_wn + H * F + (e - H * (a.Fe + 2 * F))] = t;
+      part[o_wn + H * F + (e - H * (a.Fe + 2 * F + (EGNN ? 1 : 0)))] = t;
     }
   }
   REGION_PROF(8);
@@ -1974,7 +1975,7 @@ __global__ void __launch_bounds__(64 * kRegionWaves) k_region_bwd_src(RegionLaye
               const float v = group_sum(t[0] + t[1]);
               out = l == k ? fmaf(gs[k], 1.f + s_row, -v) : out;
             }
-            if (ok && l < 3) gpos[(int64_t)(rb.n0 + s0 + r) * 3 + l] = out;
+            if (gpos && ok && l < 3) gpos[(int64_t)(rb.n0 + s0 + r) * 3 + l] = out;
           }
         });
   }
@@ -2120,7 +2121,7 @@ int32_t check_layer(const mpnn_island_layer* d, bool backward, const char* who) 
   if (backward) {
     if (!d->gy || !d->partial || d->ldgy < d->H) return fail(MPNN_E_INVALID, "%s: gy / partial missing", who);
     if (d->gx && (!d->gx_part || d->ldgx < d->F)) return fail(MPNN_E_INVALID, "%s: gx needs gx_part and ldgx >= F", who);
-    if (egnn && (!d->gpos_out || !d->gpos)) return fail(MPNN_E_INVALID, "%s: pos without gpos_out / gpos", who);
+    if (egnn && !d->gpos_out) return fail(MPNN_E_INVALID, "%s: pos without gpos_out", who);
   }
   return MPNN_OK;
 }
@@ -2170,7 +2171,7 @@ int32_t check_region(const mpnn_island_layer* d, int32_t max_nodes, bool backwar
   if (backward) {
     if (!d->gy || !d->partial || d->ldgy < d->H) return fail(MPNN_E_INVALID, "%s: gy / partial missing", who);
     if (d->gx && (!d->gx_part || d->ldgx < d->F)) return fail(MPNN_E_INVALID, "%s: gx needs gx_part and ldgx >= F", who);
-    if (egnn && (!d->gpos_out || !d->gpos)) return fail(MPNN_E_INVALID, "%s: pos without gpos_out / gpos", who);
+    if (egnn && !d->gpos_out) return fail(MPNN_E_INVALID, "%s: pos without gpos_out", who);
   }
   return MPNN_OK;
 }
@@ -2190,10 +2191,8 @@ void launch_region(const RegionLayer& r, int kind, int blocks, int64_t lds, hipS
     allow_lds(k_region_fwd<T, FEW, FW, EGNN>, id, lds);
     k_region_fwd<T, FEW, FW, EGNN><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
   } else if (kind == 1 && r.wnb) {
-    if constexpr (!EGNN) {
-      allow_lds(k_region_bwd<T, FEW, FW, false, true>, id | 24, lds);   // (kind 3 in the id)
-      k_region_bwd<T, FEW, FW, false, true><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
-    }
+    allow_lds(k_region_bwd<T, FEW, FW, EGNN, true>, id | 24, lds);   // (kind 3 in the id)
+    k_region_bwd<T, FEW, FW, EGNN, true><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
   } else if (kind == 1) {
     allow_lds(k_region_bwd<T, FEW, FW, EGNN, false>, id, lds);
     k_region_bwd<T, FEW, FW, EGNN, false><<<blocks, 64 * kRegionWaves, lds, stream>>>(r);
@@ -2360,9 +2359,10 @@ int32_t mpnn_region_layer_bwd(const mpnn_island_layer* d, int32_t max_nodes, con
   r.srow = ga + d->num_nodes * d->H;   // (read and written with coordinates only)
   r.aggr = const_cast<float*>(aggr);
   const int blocks = d->n_islands * r.groups;
-  // Without gx (a model's first layer) and without coordinates nothing needs gB[s] itself: the first pass then takes
-  // gB^T x per edge and the pass over the sources is skipped (when the wave's share fits its slab: Fe + 3 F <= 17).
-  r.wnb = !egnn && !d->gx && d->Fe + 3 * d->F <= 17;
+  // Without gx and without the gradient of the coordinates (a model's first layer) nothing needs gB[s] itself: the
+  // first pass then takes gB^T x per edge and the pass over the sources is skipped (when the wave's share fits its
+  // slab: Fe + 3 F (+ 1 with coordinates) <= 17).
+  r.wnb = !d->gx && !(egnn && d->gpos) && d->Fe + 3 * d->F + (egnn ? 1 : 0) <= 17;
   if (blocks > 0) {
     dispatch_region(r, d->dtype, 1, blocks, region_lds_floats(r.cap, true, egnn) * 4, stream);
     MPNN_LAUNCH_CHECK("k_region_bwd");

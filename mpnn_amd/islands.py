@@ -139,7 +139,7 @@ def _region_forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w
     return y, pos_out, (saved + (pos, w_pos) if plan.egnn else saved)
 
 
-def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None):
+def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None, need_pos=True):
     x, ea_s, w_nodes, w_edge, w_out, aggr, ea_t = saved[:7]
     pos, w_pos = saved[7:9] if plan.egnn else (None, None)
     if aggr is not None and (aggr.dtype != torch.float32 or not aggr.is_contiguous()):
@@ -159,7 +159,7 @@ def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=N
     gpos = g_wpos = None
     if plan.egnn:
         gpos_out = gpos_out.contiguous().float()
-        gpos = torch.empty_like(pos)
+        gpos = torch.empty_like(pos) if need_pos else None     # (not wanted: a first layer's backward is one pass shorter)
         g_wpos = torch.empty_like(w_pos)
         d.gpos_out, d.gpos, d.g_wpos = _lib.ptr(gpos_out), _lib.ptr(gpos), _lib.ptr(g_wpos)
     d.gx, d.ldgx = _lib.ptr(gx), (gx.stride(0) if gx is not None else 0)
@@ -199,11 +199,11 @@ def forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, po
     return y, pos_out, (x, ea_s, w_nodes, w_edge, w_out, pos, w_pos)
 
 
-def backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None):
+def backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None, need_pos=True):
     """Gradients of one layer.  ``needs`` = (x, w_nodes, w_edge, w_out) wanted; returns (gx, g_wn, g_we, g_wout,
     gpos, g_wpos), None where not wanted (gpos / g_wpos only for the EGNN form)."""
     if plan.region_nodes:
-        return _region_backward(plan, graph, gy, y, saved, needs, gpos_out)
+        return _region_backward(plan, graph, gy, y, saved, needs, gpos_out, need_pos)
     x, ea_s, w_nodes, w_edge, w_out, pos, w_pos = saved
     need_x, need_wn, need_we, need_wout = needs
     lib = _lib.load()

@@ -226,7 +226,8 @@ class _EgnnLayerFn(torch.autograd.Function):
         if ctx.plan is not None:
             y, *saved = ctx.saved_tensors
             needs = tuple(ctx.needs_input_grad[i] for i in (0, 3, 4, 5))
-            gx, g_wn, g_we, g_wout, g_pos, g_wp = islands.backward(ctx.plan, ctx.graph, gy, y, tuple(saved), needs, gp)
+            gx, g_wn, g_we, g_wout, g_pos, g_wp = islands.backward(ctx.plan, ctx.graph, gy, y, tuple(saved), needs, gp,
+                                                                   need_pos=ctx.needs_input_grad[1])
             w_pos_shape = ctx.w_pos_shape
             return (gx, g_pos if ctx.needs_input_grad[1] else None, None, g_wn, g_we, g_wout,
                     g_wp.reshape(w_pos_shape) if ctx.needs_input_grad[6] else None, None)

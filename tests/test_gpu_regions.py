@@ -162,11 +162,12 @@ def test_region_egnn_layer_outputs_and_every_gradient(dtype, f, fe, max_nodes):
                                        params["linear_out.weight"], params["coord_linear.weight"])
     ((want * r.double()).sum() + (want_pos * rp.double()).sum()).backward()
 
-    def run():
+    def run(inputs_need_grad=True):
         lay = layer.to(DEV).to(dtype)
         for p in lay.parameters():
             p.grad = None
-        xg, pg = x.to(DEV).clone().requires_grad_(True), pos.to(DEV).clone().requires_grad_(True)
+        xg = x.to(DEV).clone().requires_grad_(inputs_need_grad)
+        pg = pos.to(DEV).clone().requires_grad_(inputs_need_grad)
         y, pos_out = lay(xg, pg, ei.to(DEV), ea.to(DEV))
         ((y.float() * r.to(DEV)).sum() + (pos_out * rp.to(DEV)).sum()).backward()
         return y, pos_out, xg.grad, pg.grad, {k: p.grad.clone() for k, p in lay.named_parameters()}
@@ -187,6 +188,11 @@ def test_region_egnn_layer_outputs_and_every_gradient(dtype, f, fe, max_nodes):
     y2, pos2, gx2, gpos2, grads2 = run()
     assert torch.equal(y2, y) and torch.equal(pos2, pos_out) and torch.equal(gx2, gx) and torch.equal(gpos2, gpos)
     assert all(torch.equal(grads2[k], grads[k]) for k in grads)
+    # a model's first layer: neither x nor pos wants a gradient, and the backward is one pass shorter
+    y3, pos3, gx3, gpos3, grads3 = run(inputs_need_grad=False)
+    assert gx3 is None and gpos3 is None and torch.equal(y3, y) and torch.equal(pos3, pos_out)
+    for k, g in grads3.items():
+        assert_close(g.float(), params[k].grad, rtol, atol_scale=4.0, what=f"first layer: grad {k}", kink_frac=kink)
 
 
 def test_knn_clouds_egnn_layer_agrees_with_the_general_path(monkeypatch):
