@@ -460,10 +460,15 @@ __device__ __forceinline__ void block_outer(float* out, int K, int c0, int col0,
 constexpr int kTileRows = 32;
 constexpr int kStageEdges = 32;
 __host__ __device__ inline int island_pitch(int width) { return width % 8 == 4 ? width : width + 4; }   // width % 4 == 0
+// The tile [x | aggr] is read 4 bytes per lane when the widths do not allow 16-byte reads (row = lane): its rows
+// then want an ODD pitch (32 rows in 32 different banks; the 16-byte pitch rule puts rows 8 apart into one bank).
+// The tile is laid out for the wider of the two pitches either way.
+__host__ __device__ inline int island_x_room(int width) { return island_pitch(width) + 1; }
+__host__ __device__ inline int island_x_pitch(int width, bool vec) { return island_pitch(width) + (vec ? 0 : 1); }
 __host__ __device__ inline int island_stage_floats(int Fe) { return kTileRows + 8 + kStageEdges + kStageEdges * kIslandFeMax; }
 __host__ __device__ inline int island_wave_floats(int F, int H, int Fe, bool egnn, bool backward, bool xg = false) {
   const int Fp = xg ? 0 : (F + 3) & ~3;   // xg: the rows of x stay in global memory
-  return kTileRows * (island_pitch(Fp + H) + island_pitch(2 * H) + (backward ? island_pitch(H) : 0)) +
+  return kTileRows * (island_x_room(Fp + H) + island_pitch(2 * H) + (backward ? island_pitch(H) : 0)) +
          (island_stage_floats(Fe) + 3) / 4 * 4 + (egnn ? kTileRows * 4 * (backward ? 3 : 1) : 0);
 }
 
@@ -704,9 +709,9 @@ __global__ void __launch_bounds__(256) k_island_fwd(IslandLayer a) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
   const int F = a.F, Fp = (F + 3) & ~3;
-  const int px = island_pitch(Fp + H), pab = island_pitch(2 * H);
+  const int px = island_x_pitch(Fp + H, VEC), pab = island_pitch(2 * H);
   float* xa = lds + kIslandHeader + w * island_wave_floats(F, H, a.Fe, EGNN, false);
-  float* ab = xa + kTileRows * px;
+  float* ab = xa + kTileRows * island_x_room(Fp + H);
   float* stage = ab + kTileRows * pab;
   float* ps = stage + (island_stage_floats(a.Fe) + 3) / 4 * 4;
   const Unit un = island_unit(a, blockIdx.x * wpb + w);
@@ -775,12 +780,12 @@ __global__ void __launch_bounds__(256) k_island_bwd(IslandLayer a) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wpb = blockDim.x >> 6;
   const int F = a.F, Fp = XG ? 0 : (F + 3) & ~3;   // XG: no columns of x in the tile
-  const int px = island_pitch(Fp + H), pab = island_pitch(2 * H), pz = island_pitch(H);
+  const int px = island_x_pitch(Fp + H, VEC), pab = island_pitch(2 * H), pz = island_pitch(H);
   const int wave_floats = island_wave_floats(F, H, a.Fe, EGNN, true, XG);
   int* nrows = reinterpret_cast<int*>(lds);
   int* n0s = nrows + 4;
   float* tiles = lds + kIslandHeader;
-  const int o_ab = kTileRows * px, o_gz = o_ab + kTileRows * pab, o_stage = o_gz + kTileRows * pz;
+  const int o_ab = kTileRows * island_x_room(Fp + H), o_gz = o_ab + kTileRows * pab, o_stage = o_gz + kTileRows * pz;
   const int o_ps = o_stage + (island_stage_floats(a.Fe) + 3) / 4 * 4;
   float* xa = tiles + w * wave_floats;
   float* ab = xa + o_ab;
