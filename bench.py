@@ -411,6 +411,9 @@ def main():
     ap.add_argument("--no-model-step", action="store_true", help="skip the whole-model training step timing")
     ap.add_argument("--hip-graph", action="store_true",
                     help="capture one step (forward+backward) into a HIP graph and time replays (single GPU)")
+    ap.add_argument("--backward-on-caller", action="store_true",
+                    help="run the backward on the calling thread (torch.autograd.set_multithreading_enabled(False)): "
+                         "no hand-over to autograd's device thread, which matters for launch-bound eager steps")
     ap.add_argument("--first-layer", action="store_true",
                     help="time the layer as the FIRST layer of a model: x is data, no gradient with respect to x "
                          "(default: a middle layer, every gradient including the input's)")
@@ -548,6 +551,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.backward_on_caller:
+        torch.autograd.set_multithreading_enabled(False)
     for _ in range(args.warmup):
         step()
     fence()
@@ -652,7 +657,8 @@ def main():
                            (f"data parallel x{world}: one batch per rank + gradient all-reduce" if data_parallel
                             else f"dst-range partition x{world} + halo exchange ({exchange['mode']})")
                            + f" ({dist.get_backend()} reports {dist.get_world_size()} ranks)"),
-                       "launch": "HIP graph replay" if run_step is not step else "eager"},
+                       "launch": "HIP graph replay" if run_step is not step else (
+                           "eager, backward on the calling thread" if args.backward_on_caller else "eager")},
             "roofline": roofline,
             "kernels": per_kernel,
             "message_passing_only": {

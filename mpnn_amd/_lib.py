@@ -190,11 +190,20 @@ def ptr(t) -> int | None:
 def stream_handle(device) -> int:
     """The current stream of ``device``, which must be the current device: the library launches on the device that
     is current in the calling thread (wrap calls on another GPU's tensors in ``torch.cuda.device(...)``)."""
-    index = device.index if device.index is not None else torch.cuda.current_device()
-    if index != torch.cuda.current_device():
-        raise MpnnError(f"tensors live on cuda:{index} but cuda:{torch.cuda.current_device()} is the current device; "
+    current = torch.cuda.current_device()
+    index = device.index if device.index is not None else current
+    if index != current:
+        raise MpnnError(f"tensors live on cuda:{index} but cuda:{current} is the current device; "
                         "run the call under torch.cuda.device(tensor.device)")
-    return torch.cuda.current_stream(device).cuda_stream
+    return _raw_stream(index)
+
+
+def _raw_stream_slow(index: int) -> int:
+    return torch.cuda.current_stream(index).cuda_stream
+
+
+# the handle without the Stream object around it (a fifth of the cost; every library call asks for it)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", _raw_stream_slow)
 
 
 def dtype_code(dtype) -> int:

@@ -19,7 +19,7 @@ _SCRATCH = {}
 def _scratch(n: int, device) -> torch.Tensor:
     """Partial-tile scratch of the weight-gradient products, one buffer per (device, stream): calls on one stream
     reuse it in stream order, calls on different streams never share it."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _lib.stream_handle(device))
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < n:
         buf = torch.empty(n, dtype=torch.float32, device=device)
@@ -33,7 +33,7 @@ _WSPLIT = {}
 def _wsplit(nbytes: int, device) -> torch.Tensor:
     """Room for the split weight images of one NT product.  One buffer per device and stream-ordered reuse: every
     call rewrites it before its own GEMM reads it, on the stream both run on."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _lib.stream_handle(device))
     buf = _WSPLIT.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

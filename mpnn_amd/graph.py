@@ -391,7 +391,7 @@ class MPGraph:
     def scratch(self, name: str, shape, dtype, device) -> torch.Tensor:
         """Reusable scratch slabs (partial sums of split rows, gradient partials), one set per stream: calls on
         one stream reuse them in stream order, calls on different streams never share them."""
-        key = (name, tuple(shape), dtype, torch.cuda.current_stream(device).cuda_stream)
+        key = (name, tuple(shape), dtype, _lib.stream_handle(device))
         buf = self._scratch.get(key)
         if buf is None:
             buf = torch.empty(shape, dtype=dtype, device=device)
@@ -410,16 +410,15 @@ _CACHE: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
 _CACHE_SIZE = 8
 
 
-@torch.compiler.disable
-def graph_for(edge_index: torch.Tensor, num_nodes: int) -> MPGraph:
+def graph_for_eager(edge_index: torch.Tensor, num_nodes: int) -> MPGraph:
     """Cached MPGraph of ``edge_index``.
 
     The cache entry holds a reference to the tensor, so its storage address cannot be
     recycled for another edge list while the entry is alive; an in-place edit bumps
     ``_version`` and misses.
     """
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
-           str(edge_index.device), int(num_nodes))
+    key = (edge_index.data_ptr(), edge_index._version, edge_index.shape, edge_index.stride(), edge_index.device,
+           int(num_nodes))
     hit = _CACHE.get(key)
     if hit is not None:
         _CACHE.move_to_end(key)
@@ -431,10 +430,15 @@ def graph_for(edge_index: torch.Tensor, num_nodes: int) -> MPGraph:
     return g
 
 
+# for callers that may be traced (the same function behind the marker that keeps a tracing compiler out; callers
+# that know they run eagerly save the marker's few microseconds per call)
+graph_for = torch.compiler.disable(graph_for_eager)
+
+
 def register_graph(edge_index: torch.Tensor, num_nodes: int, g: MPGraph) -> None:
     """Puts a ready-made MPGraph into the cache under the key graph_for() will compute for ``edge_index``."""
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), tuple(edge_index.stride()),
-           str(edge_index.device), int(num_nodes))
+    key = (edge_index.data_ptr(), edge_index._version, edge_index.shape, edge_index.stride(), edge_index.device,
+           int(num_nodes))
     _CACHE[key] = (edge_index, g)
     _CACHE.move_to_end(key)
     while len(_CACHE) > _CACHE_SIZE:

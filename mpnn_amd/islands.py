@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import struct
 
 import torch
 
@@ -32,11 +33,12 @@ REGION_MAX_NODES = 2048
 
 
 class Plan:
-    __slots__ = ("rows", "tail_units", "egnn", "region_nodes")
+    __slots__ = ("rows", "tail_units", "egnn", "region_nodes", "partial_key", "partial_floats")
 
     def __init__(self, rows, tail_units, egnn, region_nodes=0):
         self.rows, self.tail_units, self.egnn = rows, tail_units, egnn
         self.region_nodes = region_nodes      # > 0: the region form, with this bound on the largest island
+        self.partial_key, self.partial_floats = None, 0
 
 
 def plan_for(graph: MPGraph, f: int, h: int, fe: int, egnn: bool) -> Plan | None:
@@ -78,18 +80,45 @@ def _region_plan(isl, f: int, h: int, fe: int, egnn: bool, num_nodes: int) -> Pl
     return Plan(ROWS, 0, egnn, isl.max_nodes)
 
 
-def _desc(plan: Plan, graph: MPGraph, x, ea_s, w_nodes, w_edge, w_out, y, pos=None, w_pos=None) -> _lib.IslandLayerDesc:
+# struct mpnn_island_layer, field for field (the layout _lib.IslandLayerDesc declares): one packing call fills it
+_DESC = struct.Struct("@PPPiiiq" "Pq" "PPPP" "PP" "iiii" "PqP" "PqP" "PqP" "PPPP" "PP")
+assert _DESC.size == ctypes.sizeof(_lib.IslandLayerDesc)
+
+
+def _desc(plan: Plan, graph: MPGraph, x, ea_s, w_nodes, w_edge, w_out, y, pos=None, w_pos=None, pos_out=None,
+          gy=None, gpos_out=None, gx=None, gpos=None, g_wn=None, g_we=None, g_wout=None, g_wpos=None,
+          partial=None, gx_part=None) -> _lib.IslandLayerDesc:
     isl, csr = graph.islands, graph.dst_rows
     d = _lib.IslandLayerDesc()
-    P = _lib.ptr
-    d.rowptr, d.col, d.island_ptr = P(csr.rowptr), P(csr.col), P(isl.ptr)
-    d.n_islands, d.tail_units, d.rows, d.num_nodes = isl.count, plan.tail_units, plan.rows, x.size(0)
-    d.x, d.ldx = P(x), x.stride(0)
-    d.ea, d.w_nodes, d.w_edge, d.w_out = P(ea_s), P(w_nodes), P(w_edge), P(w_out)
-    d.pos, d.w_pos = P(pos), P(w_pos)
-    d.F, d.H, d.Fe, d.dtype = x.size(1), w_out.size(0), ea_s.size(1), _lib.dtype_code(x.dtype)
-    d.y, d.ldy = P(y), y.stride(0)
+    P = lambda t: 0 if t is None else t.data_ptr()
+    _DESC.pack_into(
+        d, 0, csr.rowptr.data_ptr(), csr.col.data_ptr(), isl.ptr.data_ptr(),
+        isl.count, plan.tail_units, plan.rows, x.size(0),
+        x.data_ptr(), x.stride(0),
+        ea_s.data_ptr(), w_nodes.data_ptr(), w_edge.data_ptr(), w_out.data_ptr(),
+        P(pos), P(w_pos),
+        x.size(1), w_out.size(0), ea_s.size(1), _lib.dtype_code(x.dtype),
+        y.data_ptr(), y.stride(0), P(pos_out),
+        P(gy), 0 if gy is None else gy.stride(0), P(gpos_out),
+        P(gx), 0 if gx is None else gx.stride(0), P(gpos),
+        P(g_wn), P(g_we), P(g_wout), P(g_wpos),
+        P(partial), P(gx_part))
     return d
+
+
+def _partial_floats(plan: Plan, graph: MPGraph, f: int, h: int, fe: int) -> int:
+    """Floats of the per-block partial weight gradients of the plan's backward (asked once per plan and shape)."""
+    key = (graph.islands.count, f, h, fe)
+    if plan.partial_key != key:
+        lib = _lib.load()
+        if plan.region_nodes:
+            floats = lib.mpnn_region_layer_partial_floats(key[0], plan.region_nodes, f, h, fe, int(plan.egnn))
+        else:
+            floats = lib.mpnn_island_layer_partial_floats(key[0], plan.tail_units, f, h, fe, int(plan.egnn))
+        if floats < 0:
+            raise _lib.MpnnError("the layer's shape was rejected when asking for the size of its partial sums")
+        plan.partial_key, plan.partial_floats = key, floats
+    return plan.partial_floats
 
 
 def _inputs(x, edge_attr, w_nodes, w_edge, w_out, graph: MPGraph):
@@ -130,8 +159,7 @@ def _region_forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w
     if plan.egnn:
         pos, w_pos = pos.contiguous(), w_pos.contiguous()
         pos_out = torch.empty_like(pos)
-    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
-    d.pos_out = _lib.ptr(pos_out)
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos, pos_out)
     with _Timed("region_layer_fwd", x.device):
         _lib.check(lib.mpnn_region_layer_fwd(ctypes.byref(d), plan.region_nodes, _lib.ptr(aggr),
                                              _lib.stream_handle(x.device)), "mpnn_region_layer_fwd")
@@ -150,8 +178,6 @@ def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=N
     n, f = x.shape
     h = w_out.size(0)
     gy = gy if gy.is_contiguous() else gy.contiguous()
-    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
-    d.gy, d.ldgy = _lib.ptr(gy), gy.stride(0)
     gx = torch.empty((n, f), dtype=dt, device=dev) if need_x else None
     g_wn = torch.empty_like(w_nodes) if need_wn else None
     g_we = torch.empty_like(w_edge) if need_we else None
@@ -161,16 +187,12 @@ def _region_backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=N
         gpos_out = gpos_out.contiguous().float()
         gpos = torch.empty_like(pos) if need_pos else None     # (not wanted: a first layer's backward is one pass shorter)
         g_wpos = torch.empty_like(w_pos)
-        d.gpos_out, d.gpos, d.g_wpos = _lib.ptr(gpos_out), _lib.ptr(gpos), _lib.ptr(g_wpos)
-    d.gx, d.ldgx = _lib.ptr(gx), (gx.stride(0) if gx is not None else 0)
-    d.g_wn, d.g_we, d.g_wout = _lib.ptr(g_wn), _lib.ptr(g_we), _lib.ptr(g_wout)
-    floats = lib.mpnn_region_layer_partial_floats(graph.islands.count, plan.region_nodes, f, h, ea_s.size(1), int(plan.egnn))
-    if floats < 0:
-        raise _lib.MpnnError("mpnn_region_layer_partial_floats rejected the layer's shape")
-    d.partial = _lib.ptr(graph.scratch("region_partial", (max(floats, 1),), torch.float32, dev))
-    if need_x:
-        d.gx_part = _lib.ptr(graph.scratch("region_gx", (n, f), torch.float32, dev))
+    floats = _partial_floats(plan, graph, f, h, ea_s.size(1))
+    partial = graph.scratch("region_partial", (max(floats, 1),), torch.float32, dev)
+    gx_part = graph.scratch("region_gx", (n, f), torch.float32, dev) if need_x else None
     ga = graph.scratch("region_ga", (n * h + n,), torch.float32, dev)     # (+ one float per node with coordinates)
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos, None, gy, gpos_out, gx, gpos, g_wn, g_we,
+              g_wout, g_wpos, partial, gx_part)
     src = graph.by_src
     with _Timed("region_layer_bwd", dev):
         _lib.check(lib.mpnn_region_layer_bwd(ctypes.byref(d), plan.region_nodes, _lib.ptr(src.rowptr), _lib.ptr(src.col),
@@ -192,8 +214,7 @@ def forward(plan: Plan, graph: MPGraph, x, edge_attr, w_nodes, w_edge, w_out, po
         pos = pos.contiguous()
         w_pos = w_pos.contiguous()
         pos_out = torch.empty_like(pos)
-    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
-    d.pos_out = _lib.ptr(pos_out)
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos, pos_out)
     with _Timed("island_layer_fwd", x.device):
         _lib.check(lib.mpnn_island_layer_fwd(ctypes.byref(d), _lib.stream_handle(x.device)), "mpnn_island_layer_fwd")
     return y, pos_out, (x, ea_s, w_nodes, w_edge, w_out, pos, w_pos)
@@ -211,8 +232,6 @@ def backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None, nee
     n, f = x.shape
     h = w_out.size(0)
     gy = gy if gy.is_contiguous() else gy.contiguous()
-    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos)
-    d.gy, d.ldgy = _lib.ptr(gy), gy.stride(0)
     gx = torch.empty((n, f), dtype=dt, device=dev) if need_x else None
     g_wn = torch.empty_like(w_nodes) if need_wn else None
     g_we = torch.empty_like(w_edge) if need_we else None
@@ -222,17 +241,11 @@ def backward(plan: Plan, graph: MPGraph, gy, y, saved, needs, gpos_out=None, nee
         gpos_out = gpos_out.contiguous().float()
         gpos = torch.empty_like(pos)
         g_wpos = torch.empty_like(w_pos)
-        d.gpos_out, d.gpos, d.g_wpos = _lib.ptr(gpos_out), _lib.ptr(gpos), _lib.ptr(g_wpos)
-    d.gx, d.ldgx = _lib.ptr(gx), (gx.stride(0) if gx is not None else 0)
-    d.g_wn, d.g_we, d.g_wout = _lib.ptr(g_wn), _lib.ptr(g_we), _lib.ptr(g_wout)
-    isl = graph.islands
-    floats = lib.mpnn_island_layer_partial_floats(isl.count, plan.tail_units, f, h, ea_s.size(1), int(plan.egnn))
-    if floats < 0:
-        raise _lib.MpnnError("mpnn_island_layer_partial_floats rejected the layer's shape")
+    floats = _partial_floats(plan, graph, f, h, ea_s.size(1))
     partial = graph.scratch("island_partial", (max(floats, 1),), torch.float32, dev)
-    d.partial = _lib.ptr(partial)
-    if need_x:
-        d.gx_part = _lib.ptr(graph.scratch("island_gx", (n, f), torch.float32, dev))
+    gx_part = graph.scratch("island_gx", (n, f), torch.float32, dev) if need_x else None
+    d = _desc(plan, graph, x, ea_s, w_nodes, w_edge, w_out, y, pos, w_pos, None, gy, gpos_out, gx, gpos, g_wn, g_we,
+              g_wout, g_wpos, partial, gx_part)
     with _Timed("island_layer_bwd", dev):
         _lib.check(lib.mpnn_island_layer_bwd(ctypes.byref(d), _lib.stream_handle(dev)), "mpnn_island_layer_bwd")
     return gx, g_wn, g_we, g_wout, gpos, g_wpos

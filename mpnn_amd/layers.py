@@ -18,7 +18,7 @@ import torch
 from torch.nn import Linear
 
 from . import compiled_ops, layer_fn
-from .graph import graph_for
+from .graph import graph_for, graph_for_eager
 
 
 class _SplitCatWeight(torch.autograd.Function):
@@ -55,8 +55,8 @@ class MPNNLayerCat(torch.nn.Module):
         w_nodes, w_edge = _SplitCatWeight.apply(self.linear.weight, self.in_channels)
         if torch.compiler.is_compiling():      # torch.compile(model), experiments/flickr_exp.py:30: one opaque operator
             return compiled_ops.layer(x, edge_index, edge_attr, w_nodes, w_edge, self.linear_out.weight)
-        graph = graph_for(edge_index, x.size(0))
-        return layer_fn.layer_forward(x, edge_attr, w_nodes, w_edge, self.linear_out.weight, graph)
+        graph = graph_for_eager(edge_index, x.size(0))
+        return layer_fn.layer_forward_eager(x, edge_attr, w_nodes, w_edge, self.linear_out.weight, graph)
 
 
 class MPNNLayerSum(torch.nn.Module):
@@ -72,9 +72,9 @@ class MPNNLayerSum(torch.nn.Module):
         if torch.compiler.is_compiling():      # torch.compile(model), experiments/flickr_exp.py:30: one opaque operator
             return compiled_ops.layer(x, edge_index, edge_attr, self.fused_linear.weight, self.linear_3.weight,
                                       self.linear_out.weight)
-        graph = graph_for(edge_index, x.size(0))
-        return layer_fn.layer_forward(x, edge_attr, self.fused_linear.weight, self.linear_3.weight,
-                                      self.linear_out.weight, graph)
+        graph = graph_for_eager(edge_index, x.size(0))
+        return layer_fn.layer_forward_eager(x, edge_attr, self.fused_linear.weight, self.linear_3.weight,
+                                            self.linear_out.weight, graph)
 
 
 class EGNNLayer(torch.nn.Module):
@@ -97,6 +97,10 @@ class EGNNLayer(torch.nn.Module):
         self.coord_linear = Linear(out_channels, 1, bias=False)
 
     def forward(self, x, pos, edge_index, edge_attr):
-        graph = graph_for(edge_index, x.size(0))
-        return layer_fn.egnn_layer_forward(x, pos, edge_attr, self.fused_linear.weight, self.linear_3.weight,
-                                           self.linear_out.weight, self.coord_linear.weight.view(-1), graph)
+        if torch.compiler.is_compiling():      # under a tracing compiler: the marked forms (a graph break each)
+            graph = graph_for(edge_index, x.size(0))
+            return layer_fn.egnn_layer_forward(x, pos, edge_attr, self.fused_linear.weight, self.linear_3.weight,
+                                               self.linear_out.weight, self.coord_linear.weight.view(-1), graph)
+        graph = graph_for_eager(edge_index, x.size(0))
+        return layer_fn.egnn_layer_forward_eager(x, pos, edge_attr, self.fused_linear.weight, self.linear_3.weight,
+                                                 self.linear_out.weight, self.coord_linear.weight.view(-1), graph)

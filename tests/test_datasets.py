@@ -118,3 +118,29 @@ def test_epoch_loops_with_the_reference_signatures(capsys):
     train.Train_ModelNet_FB(mm, mn.get_full_graphs(), mo, F.cross_entropy, "cuda", epochs=2)
     out = capsys.readouterr().out
     assert "Validation Loss: " in out and out.count("| Test Loss: ") == 2
+
+
+@pytest.mark.gpu
+def test_backward_on_the_calling_thread_gives_the_same_gradients():
+    """mpnn_amd.train.backward_on_caller (what the trainers wrap their loss.backward() in) only changes WHERE the
+    backward runs: every gradient is bit for bit the one autograd's device thread produces."""
+    from mpnn_amd import MPNN_QM9, synth
+    from mpnn_amd.train import backward_on_caller
+    d = synth.qm9(torch.device("cuda:0"), 3, 64)
+    torch.manual_seed(0)
+    model = MPNN_QM9(11, 4, 64, 19, num_layers=2, mode="sum").cuda()
+
+    def grads(scoped):
+        model.zero_grad()
+        loss = F.mse_loss(model(d["x"], d["edge_index"], d["batch"], d["edge_attr"])[0], d["y"][0])
+        if scoped:
+            with backward_on_caller():
+                assert not torch.autograd.is_multithreading_enabled()
+                loss.backward()
+        else:
+            loss.backward()
+        return [p.grad.clone() for p in model.parameters()]
+
+    there, here = grads(False), grads(True)
+    assert torch.autograd.is_multithreading_enabled()          # scoped: back on after the with
+    assert all(torch.equal(a, b) for a, b in zip(there, here))

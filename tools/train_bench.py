@@ -16,6 +16,9 @@ from mpnn_amd.data import GraphStore
 from mpnn_amd.graph import clear_cache
 
 dev = torch.device("cuda:0")
+if "caller" in sys.argv[1:]:       # every backward on the calling thread (mpnn_amd.train.backward_on_caller, here for the whole run)
+    torch.autograd.set_multithreading_enabled(False)
+    print("backward on the calling thread", flush=True)
 
 
 def run(name, store, model, loss_fn, batch_size, steps=60, warmup=15):
