@@ -222,8 +222,12 @@ int32_t mpnn_collate(const mpnn_collate_desc* desc, mpnn_stream_t stream);
  * part_out, part_cnt  float [n_parts, H] scratch for split rows (part_cnt may be NULL
  *           iff cnt is NULL); may be NULL when n_parts == 0
  * maskbits  optional uint32 [E, mpnn_mask_words(H, dtype)], 16-byte aligned: per CSR position the
- *           relu mask of the message, one bit per column (word v, bit l <=> column l * words + v),
- *           consumed by mpnn_aggregate_bwd_src_masked; needs cnt != NULL; pass NULL when
+ *           relu mask of the message, one bit per column, in a layout private to this call and
+ *           mpnn_aggregate_bwd_src_masked, which consumes it (bfloat16 rows of 33..128 columns: one byte
+ *           per 8 columns, bit 7 - v of byte l <=> column 8 l + v, 8 or 16 bytes per edge; otherwise
+ *           word v, bit l <=> column l * words + v); a NaN message counts as positive in the bfloat16
+ *           byte layout (torch's relu backward would give it 0; the forward output is NaN either way);
+ *           needs cnt != NULL; pass NULL when
  *           mpnn_mask_words(H, dtype) == 0 (H too wide or not a multiple of the vector width)
  * Requirements: H % 4 == 0 (f32) or H % 8 == 0 (bf16) for the vector path, otherwise a
  * scalar path is used; base pointers 16-byte aligned and ld* % vector width == 0 for

@@ -31,6 +31,86 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // Streams that are read once (index lists, mask words) can bypass the cache hierarchy's retention so that the
 // gathered rows, some of which are re-read often (targets of high in-degree), keep the L2.
 #define NT_LOAD(p) __builtin_nontemporal_load(p)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// edge_term for pairs of columns, as vector arithmetic (v_pk_mul_f32 / v_pk_fma_f32): per column the same multiply
+// and fma chain in f order.
+template <int VEC, int FE>
+__device__ __forceinline__ void edge_term_pairs(const float (&w)[VEC][FE], const float (&e)[FE], float (&ce)[VEC]) {
+#pragma unroll
+  for (int q = 0; q < VEC / 2; ++q) {
+    f32x2 s = f32x2{w[2 * q][0], w[2 * q + 1][0]} * f32x2{e[0], e[0]};
+#pragma unroll
+    for (int f = 1; f < FE; ++f)
+      s = __builtin_elementwise_fma(f32x2{w[2 * q][f], w[2 * q + 1][f]}, f32x2{e[f], e[f]}, s);
+    ce[2 * q] = s.x;
+    ce[2 * q + 1] = s.y;
+  }
+}
+
+// x[v] = relu(x[v]) and bits = bits << 8 | (bit 7 - v = [x[v] > 0]) for the 8 columns of a lane, as 24 instructions:
+// 8 compares into 8 scalar register pairs, 8 selects, 8 add-with-carry (bits + bits + carry shifts the compare's
+// result in).  Written out because on gfx950 a compare's scalar result may be read by a vector instruction only two
+// wait states later (the compiler pads each compare-select pair with s_nop 1, which doubles its cost); with the
+// compares grouped, every reader is at least 8 instructions behind its compare and nothing is padded.
+// The select keeps x unless 0 >= x, so NaN propagates as in torch.relu; a NaN message counts as positive here.
+__device__ __forceinline__ void relu_shift_in8(float (&x)[8], uint32_t& bits) {
+  unsigned long long c0, c1, c2, c3, c4, c5, c6, c7, carry_out;
+  asm("v_cmp_nge_f32_e64 %[c0], 0, %[x0]\n\t"
+      "v_cmp_nge_f32_e64 %[c1], 0, %[x1]\n\t"
+      "v_cmp_nge_f32_e64 %[c2], 0, %[x2]\n\t"
+      "v_cmp_nge_f32_e64 %[c3], 0, %[x3]\n\t"
+      "v_cmp_nge_f32_e64 %[c4], 0, %[x4]\n\t"
+      "v_cmp_nge_f32_e64 %[c5], 0, %[x5]\n\t"
+      "v_cmp_nge_f32_e64 %[c6], 0, %[x6]\n\t"
+      "v_cmp_nge_f32_e64 %[c7], 0, %[x7]\n\t"
+      "v_cndmask_b32_e64 %[x0], 0, %[x0], %[c0]\n\t"
+      "v_cndmask_b32_e64 %[x1], 0, %[x1], %[c1]\n\t"
+      "v_cndmask_b32_e64 %[x2], 0, %[x2], %[c2]\n\t"
+      "v_cndmask_b32_e64 %[x3], 0, %[x3], %[c3]\n\t"
+      "v_cndmask_b32_e64 %[x4], 0, %[x4], %[c4]\n\t"
+      "v_cndmask_b32_e64 %[x5], 0, %[x5], %[c5]\n\t"
+      "v_cndmask_b32_e64 %[x6], 0, %[x6], %[c6]\n\t"
+      "v_cndmask_b32_e64 %[x7], 0, %[x7], %[c7]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c0]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c1]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c2]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c3]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c4]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c5]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c6]\n\t"
+      "v_addc_co_u32_e64 %[b], %[co], %[b], %[b], %[c7]"
+      : [x0] "+v"(x[0]), [x1] "+v"(x[1]), [x2] "+v"(x[2]), [x3] "+v"(x[3]), [x4] "+v"(x[4]), [x5] "+v"(x[5]),
+        [x6] "+v"(x[6]), [x7] "+v"(x[7]), [b] "+v"(bits), [c0] "=&s"(c0), [c1] "=&s"(c1), [c2] "=&s"(c2),
+        [c3] "=&s"(c3), [c4] "=&s"(c4), [c5] "=&s"(c5), [c6] "=&s"(c6), [c7] "=&s"(c7), [co] "=&s"(carry_out));
+}
+
+// Byte transpose across the 4 W lanes of a group (W = 2 or 4 words per lane): in, byte k of lane l's words = M[l][k];
+// out, byte l of lane k's words = M[l][k].  Exchanges with the lanes 8 (W = 4 only), 4, 2 and 1 apart: word pairs,
+// words, half words, bytes.
+template <int W>
+__device__ __forceinline__ void transpose_bytes(uint32_t (&w)[W], int lig) {
+  constexpr int LANES = 4 * W;
+  if constexpr (W == 4) {
+    const bool b8 = lig & 8;
+    const uint32_t g0 = __shfl_xor(b8 ? w[0] : w[2], 8, LANES), g1 = __shfl_xor(b8 ? w[1] : w[3], 8, LANES);
+    if (b8) { w[0] = g0; w[1] = g1; } else { w[2] = g0; w[3] = g1; }
+  }
+  const bool b4 = lig & 4, b2 = lig & 2, b1 = lig & 1;
+#pragma unroll
+  for (int p = 0; p < W; p += 2) {
+    const uint32_t got = __shfl_xor(b4 ? w[p] : w[p + 1], 4, LANES);
+    if (b4) w[p] = got; else w[p + 1] = got;
+  }
+  // v_perm_b32: selector values 0-3 pick bytes of the second operand (own), 4-7 of the first (the partner's)
+  const uint32_t sel2 = b2 ? 0x03020706u : 0x05040100u;   // [own 0 1 | partner 0 1]  or  [partner 2 3 | own 2 3]
+  const uint32_t sel1 = b1 ? 0x03070105u : 0x06020400u;   // [own 0, partner 0, own 2, partner 2]  or  [partner 1, own 1, partner 3, own 3]
+#pragma unroll
+  for (int p = 0; p < W; ++p) w[p] = __builtin_amdgcn_perm(__shfl_xor(w[p], 2, LANES), w[p], sel2);
+#pragma unroll
+  for (int p = 0; p < W; ++p) w[p] = __builtin_amdgcn_perm(__shfl_xor(w[p], 1, LANES), w[p], sel1);
+}
 
 // VEC counts as bytes (saturated at 255): one 4- or 8-byte store when the lane owns that many columns.
 template <int VEC>
@@ -69,11 +149,15 @@ struct FwdArgs {
   float* part_out;
   float* part_cnt;
   uint32_t* maskbits;  // optional [E][mpnn_mask_words] words: bit `lig` of word v = (message column lig*VEC+v of this
-                       // edge > 0); 16-bit words, two per 32-bit word, when a row takes at most 16 lanes of 8 columns
+                       // edge > 0); 16-bit words, two per 32-bit word, when a row takes at most 16 lanes of 8 columns;
+                       // TRAIN >= 3 (8 or 16 lanes of 8 columns): byte `lig` of the edge's 8 or 16, bit 7 - v =
+                       // column lig*8+v
   int H; int lpr_log2;
 };
 
-// TRAIN: 0 = output only, 1 = + positive-message counts, 2 = + relu mask bits per edge.
+// TRAIN: 0 = output only, 1 = + positive-message counts, 2 = + relu mask bits per edge (votes across the lanes),
+// 3 / 4 = the same for rows of 8 / 16 lanes x 8 columns with every lane keeping the bits of its own columns (one
+// byte per edge and lane; the counts are taken from the bits, word by word).
 // Waves per SIMD the kernel is compiled for: the per-lane edge weights take VEC * FE registers, so the widest
 // instantiation (bfloat16 rows with the generic edge width) gets a larger register budget instead of spilling
 // hundreds of bytes.  (bfloat16 rows with Fe = 4 are faster at 4 waves with a 36-byte spill than at 3 without.)
@@ -94,6 +178,34 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
 
   float w[VEC][FE];
   load_edge_weights<T, VEC, FE>(a.We, a.fe, c0, act, w);
+
+  // TRAIN >= 3: the mask words of a finished chunk wait here (lane l: its own bytes of the chunk's edges) until the
+  // next chunk's gathers are in flight; the exchange that turns them into per-edge records (three dependent trips
+  // through the LDS crossbar) then runs in the shadow of those gathers instead of at the end of its own chunk.
+  constexpr int OW = TRAIN == 3 ? 2 : (TRAIN == 4 ? 4 : 0);   // mask words per lane and chunk (4 edges each)
+  constexpr bool OWN = OW > 0;
+  uint32_t pend[OWN ? OW : 1];
+#pragma unroll
+  for (int k = 0; k < (OWN ? OW : 1); ++k) pend[k] = 0u;
+  int pend_base = 0, pend_nb = 0;
+  auto flush_mask = [&]() __attribute__((always_inline)) {
+    if constexpr (OWN) {
+      // lane k of the group gets the bytes of edge pend_base + k (byte l from lane l): one coalesced 8- or 16-byte
+      // store per edge
+      transpose_bytes<OW>(pend, lig);
+      if (lig < pend_nb) {
+        uint32_t* mp = a.maskbits + (int64_t)(pend_base + lig) * OW;
+        if constexpr (OW == 2) {
+          u32x2 w2 = {pend[0], pend[1]};
+          __builtin_nontemporal_store(w2, reinterpret_cast<u32x2*>(mp));
+        } else {
+          u32x4 w4 = {pend[0], pend[1], pend[2], pend[3]};
+          __builtin_nontemporal_store(w4, reinterpret_cast<u32x4*>(mp));
+        }
+      }
+      pend_nb = 0;
+    }
+  };
 
   const int64_t wave = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   const int64_t stride = (int64_t)gridDim.x * (kBlock / 64) * gpw;
@@ -134,6 +246,12 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
       uint32_t mb[VEC < 4 ? 4 : VEC];  // relu mask words of edge base + lig, collected over the chunk
 #pragma unroll
       for (int v = 0; v < (VEC < 4 ? 4 : VEC); ++v) mb[v] = 0u;
+      // OWN: the bits of the lane's own columns, 8 per edge, shifted in from below (edge j + u of a group of 4 ends in
+      // byte 3 - u, column v in bit 7 - v of its byte); own_w[k]: edges 4 k .. 4 k + 3 of the chunk
+      uint32_t own = 0u, own_w[OWN ? OW : 1];
+#pragma unroll
+      for (int k = 0; k < (OWN ? OW : 1); ++k) own_w[k] = 0u;
+      static_assert(!OWN || (VEC == 8 && U == 4), "own-bits form: 8 columns per lane, words of 4 edges");
       for (int j = 0; j < nb; j += U) {
         typename RowIO<T, VEC>::Raw braw[U];   // rows in flight stay in their storage format
 #pragma unroll
@@ -142,6 +260,7 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
           const int s = __shfl(cur, jj, lpr);
           braw[u] = RowIO<T, VEC>::load_raw(a.B + (int64_t)s * a.ldB + cc);
         }
+        if (OWN && j == 0) flush_mask();   // the previous chunk's words, while this chunk's rows arrive
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool live = (j + u) < nb;
@@ -151,10 +270,31 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
           for (int f = 0; f < FE; ++f) ev[f] = __shfl(ecur[f], jj, lpr);
           if (live) {   // slots past the chunk's end only cost the (cached) load: their lanes sit out the arithmetic
             float ce[VEC], bv[VEC];
-            edge_term<VEC, FE>(w, ev, ce);
+            if constexpr (OWN) edge_term_pairs<VEC, FE>(w, ev, ce);
+            else edge_term<VEC, FE>(w, ev, ce);
             RowIO<T, VEC>::unpack(braw[u], bv);
+            if constexpr (OWN) {
+              // the pre-activations of column pairs on packed instructions, written as vector arithmetic: their
+              // results go into the block below lane register by lane register, and the compiler does not pair up
+              // scalar arithmetic that feeds it (same operations in the same order as the scalar form)
+              float m[VEC];
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) {
+              for (int q = 0; q < VEC / 2; ++q) {
+                const f32x2 t = (f32x2{ar[2 * q], ar[2 * q + 1]} + f32x2{bv[2 * q], bv[2 * q + 1]}) +
+                                f32x2{ce[2 * q], ce[2 * q + 1]};
+                m[2 * q] = t.x;
+                m[2 * q + 1] = t.y;
+              }
+              relu_shift_in8(m, own);
+#pragma unroll
+              for (int q = 0; q < VEC / 2; ++q) {
+                const f32x2 s2 = f32x2{acc[2 * q], acc[2 * q + 1]} + f32x2{m[2 * q], m[2 * q + 1]};
+                acc[2 * q] = s2.x;
+                acc[2 * q + 1] = s2.y;
+              }
+            }
+#pragma unroll
+            for (int v = 0; v < (OWN ? 0 : VEC); ++v) {
               const float m = relu_f((ar[v] + bv[v]) + ce[v]);
               acc[v] += m;
               if (TRAIN) {
@@ -170,8 +310,23 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
                 }
               }
             }
+          } else if (OWN) {
+            own <<= 8;   // a slot past the row's end: no bits, but the word keeps its alignment
           }
         }
+        if constexpr (OWN) {   // a word of 4 edges is complete: count its bits per column, keep it in edge order
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) cn[v] += __popc(own & (0x80808080u >> v));
+          const uint32_t done = __builtin_bswap32(own);   // byte k = edge j + k
+#pragma unroll
+          for (int k = 0; k < OW; ++k) own_w[k] = (j == 4 * k) ? done : own_w[k];
+        }
+      }
+      if constexpr (OWN) {
+#pragma unroll
+        for (int k = 0; k < OW; ++k) pend[k] = own_w[k];
+        pend_base = base;
+        pend_nb = nb;
       }
       if (TRAIN == 2 && VEC % 4 == 0) {
         // one coalesced store per chunk: lane lig writes the VEC words of edge base + lig
@@ -217,6 +372,7 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
       }
     }
   }
+  if (OWN) flush_mask();   // the last chunk's words
 }
 
 // ---------------------------------------------------------------------------------------
@@ -335,8 +491,11 @@ struct BwdMaskArgs {
   int H; int lpr_log2;
 };
 
-template <typename T, int VEC, int FE, bool RTFE, int U, bool PACK>
+// FMT: the layout of an edge's mask the forward wrote: 0 = VEC words, 1 = VEC 16-bit words, 2 = one byte per lane
+// (rows of 8 or 16 lanes x 8 columns: byte `lig`, bit 7 - v = column lig * 8 + v).
+template <typename T, int VEC, int FE, bool RTFE, int U, int FMT>
 __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a) {
+  constexpr bool PACK = FMT == 1;
   extern __shared__ float lds[];
   const int lane = threadIdx.x & 63;
   const int lpr = 1 << a.lpr_log2;
@@ -381,7 +540,10 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a)
           const int d = __shfl(cur, jj, lpr);
           const int pp = __shfl(curp, jj, lpr);
           RowIO<T, VEC>::load(a.G + (int64_t)d * a.ldG + cc, gv[u]);
-          if constexpr (PACK) {   // 16-bit words, two per 32-bit word (see the forward kernel); compile-time: a
+          if constexpr (FMT == 2) {
+            // the word that holds this lane's byte (4 lanes per word: the group reads its 8 or 16 bytes as one piece)
+            mw[u][0] = NT_LOAD(a.maskbits + (int64_t)pp * (lpr >> 2) + (lig >> 2));
+          } else if constexpr (PACK) {   // 16-bit words, two per 32-bit word (see the forward kernel); compile-time: a
                                   // load under a run-time branch would make the compiler wait for every load in flight
             const u32x4 w = NT_LOAD(reinterpret_cast<const u32x4*>(a.maskbits + (int64_t)pp * 4));
             mw[u][0] = w.x; mw[u][1 % VEC] = w.x >> 16; mw[u][2 % VEC] = w.y; mw[u][3 % VEC] = w.y >> 16;
@@ -399,12 +561,27 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a)
           }
           load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(base + jj), a.fe, ev[u]);
         }
+        // every load of the U edges goes out before the first of them is waited for (left to itself the scheduler
+        // takes this form's edges one after the other: load, wait, compute)
+        if constexpr (FMT == 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const bool live = (j + u) < nb;
+          // (FMT == 2: the bits of this lane's columns, byte lig & 3 of the word; a slot past the row's end extracts
+          // a field of width 0.  Not `live ? field : 0`: the compiler turns a select with a load behind one operand
+          // into a branch around the load, and a wait for every gather in flight with it.)
+          const uint32_t own = __builtin_amdgcn_ubfe(mw[u][0], 8 * (lig & 3), live ? 8u : 0u);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
-            const float m = (live && ((mw[u][v] >> lig) & 1u)) ? gv[u][v] : 0.f;
+            float m;
+            if constexpr (FMT == 2) {
+              // the column's bit spread over a word (0 or all ones) and'ed onto the gradient: two instructions, and
+              // no compare whose result a select would have to wait for
+              const int keep = __builtin_amdgcn_sbfe((int)own, 7 - v, 1);
+              m = __uint_as_float(__float_as_uint(gv[u][v]) & (uint32_t)keep);
+            } else {
+              m = (live && ((mw[u][v] >> lig) & 1u)) ? gv[u][v] : 0.f;
+            }
             acc[v] += m;
 #pragma unroll
             for (int f = 0; f < FE; ++f) gw[v][f] = fmaf(m, ev[u][f], gw[v][f]);
@@ -610,7 +787,11 @@ static int32_t run_fwd(const void* A, int64_t ldA, const void* B, int64_t ldB, c
   int32_t rc;
   if (!cnt) rc = launch_fwd<T, VEC, 0>(a, grid, stream);
   else if (!maskbits) rc = launch_fwd<T, VEC, 1>(a, grid, stream);
-  else if constexpr (VEC % 4 == 0) rc = launch_fwd<T, VEC, 2>(a, grid, stream);
+  else if constexpr (VEC == 8) {
+    // rows of 8 or 16 lanes: every lane keeps the bits of its own columns (4 gathers in flight: a mask word is 4 edges)
+    rc = g.lpr_log2 == 3 ? launch_fwd_u<T, VEC, 3, 4>(a, grid, stream)
+       : g.lpr_log2 == 4 ? launch_fwd_u<T, VEC, 4, 4>(a, grid, stream) : launch_fwd<T, VEC, 2>(a, grid, stream);
+  } else if constexpr (VEC % 4 == 0) rc = launch_fwd<T, VEC, 2>(a, grid, stream);
   else return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: mask bits need the 16-byte vector path");
   if (rc != MPNN_OK) return rc;
   if (n_split > 0) {
@@ -675,14 +856,15 @@ static int32_t run_bwd_masked(const void* G, int64_t ldG, const uint32_t* maskbi
   const int tile = (1 << g.lpr_log2) * VEC;
   const int fe_t = Fe == 4 ? 4 : (Fe == 1 ? 1 : kMaxFe);
   const size_t lds = (size_t)(kBlock / 64) * tile * fe_t * sizeof(float);
-  auto go = [&](auto pack) {
-    constexpr bool PACK = decltype(pack)::value;
-    if (Fe == 4) k_agg_bwd_src_masked<T, VEC, 4, false, U, PACK><<<grid, kBlock, lds, stream>>>(a);
-    else if (Fe == 1) k_agg_bwd_src_masked<T, VEC, 1, false, U, PACK><<<grid, kBlock, lds, stream>>>(a);
-    else k_agg_bwd_src_masked<T, VEC, kMaxFe, true, U, PACK><<<grid, kBlock, lds, stream>>>(a);
+  auto go = [&](auto fmt) {
+    constexpr int FMT = decltype(fmt)::value;
+    if (Fe == 4) k_agg_bwd_src_masked<T, VEC, 4, false, U, FMT><<<grid, kBlock, lds, stream>>>(a);
+    else if (Fe == 1) k_agg_bwd_src_masked<T, VEC, 1, false, U, FMT><<<grid, kBlock, lds, stream>>>(a);
+    else k_agg_bwd_src_masked<T, VEC, kMaxFe, true, U, FMT><<<grid, kBlock, lds, stream>>>(a);
   };
-  if (VEC == 8 && g.lpr_log2 <= 4) go(std::true_type{});
-  else go(std::false_type{});
+  if (VEC == 8 && (g.lpr_log2 == 3 || g.lpr_log2 == 4)) go(std::integral_constant<int, 2>{});   // the layouts run_fwd chooses
+  else if (VEC == 8 && g.lpr_log2 <= 4) go(std::integral_constant<int, 1>{});
+  else go(std::integral_constant<int, 0>{});
   MPNN_LAUNCH_CHECK("k_agg_bwd_src_masked");
   if (n_split > 0) {
     int32_t rc = launch_reduce_split<T, VEC>(part_gB, split, n_split, static_cast<T*>(gB), ldgB, H, g, stream);
@@ -874,6 +1056,7 @@ int32_t mpnn_mask_words(int32_t H, int32_t dtype) {
   if (H < 1 || (dtype != MPNN_F32 && dtype != MPNN_BF16)) return 0;
   const Geometry g = geometry(H, dtype, true);
   if (g.vec == 1 || g.tiles != 1 || g.lpr_log2 > 5) return 0;
+  if (g.vec == 8 && g.lpr_log2 == 3) return 2;          // rows of 8 lanes x 8 columns: one byte per lane
   return (g.vec == 8 && g.lpr_log2 <= 4) ? 4 : g.vec;   // rows of at most 16 lanes pack two 16-bit words per word
 }
 

@@ -54,8 +54,9 @@ def test_argument_validation_reports_errors_without_a_gpu():
     rc = lib.mpnn_csr_build(None, None, -1, 4, 4, None, None, None, None, None, 0, None)
     assert rc == -1
     assert lib.mpnn_bwd_scratch_floats(64, 4) == 2048 * 64 * 4
-    assert lib.mpnn_mask_words(128, 0) == 4 and lib.mpnn_mask_words(64, 1) == 4      # bf16 rows of <= 16 lanes pack
-    assert lib.mpnn_mask_words(128, 1) == 4 and lib.mpnn_mask_words(256, 1) == 8     # two 16-bit words per word
+    assert lib.mpnn_mask_words(128, 0) == 4 and lib.mpnn_mask_words(64, 1) == 2      # bf16 rows of 8 / 16 lanes: a byte
+    assert lib.mpnn_mask_words(128, 1) == 4 and lib.mpnn_mask_words(256, 1) == 8     # per lane; of <= 4 lanes: two
+    assert lib.mpnn_mask_words(32, 1) == 4 and lib.mpnn_mask_words(56, 1) == 2       # 16-bit words per word
     assert lib.mpnn_mask_words(7, 0) == 0 and lib.mpnn_mask_words(256, 0) == 0
     with pytest.raises(_lib.MpnnError):
         _lib.check(rc, "mpnn_csr_build")

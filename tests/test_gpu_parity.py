@@ -612,17 +612,27 @@ def test_gemm_tn_two_right_hand_matrices(n, m, k, k2, dev):
     assert torch.equal(both, gemm_tn(g, x, mask=mask, x2=x2)), "not reproducible"
 
 
-def test_recomputing_backward_matches_mask_bit_backward(dev):
-    """The two backward forms (stored relu mask bits vs. recomputed pre-activation) give the same gradients bit for bit."""
+# one case per layout of the stored mask: words of 32 lanes (fp32, H = 128) and of 16 (H = 64), 16-bit words
+# (bf16, H = 128), a byte per lane (bf16 rows of 8 lanes: H = 64, and H = 56 with an idle lane), Fe = 1 and generic
+@pytest.mark.parametrize("H,Fe,dtype", [(128, 4, torch.float32), (64, 4, torch.float32), (128, 4, torch.bfloat16),
+                                        (64, 4, torch.bfloat16), (64, 1, torch.bfloat16), (64, 3, torch.bfloat16),
+                                        (56, 4, torch.bfloat16)])
+def test_recomputing_backward_matches_mask_bit_backward(H, Fe, dtype, dev):
+    """The two backward forms (stored relu mask bits vs. recomputed pre-activation) give the same gradients bit for
+    bit, and the forward the same sums whether or not it keeps the bits (rows of every length from 0 to thousands of
+    edges: chunks with 1 to 8 edges, split rows)."""
     from mpnn_amd import ops
-    a, _, _ = _aggregate_case(dev, 400, 20000, 128, 4, seed=9, skew=True)
+    lib = ops._lib.load()
+    assert lib.mpnn_mask_words(H, ops._lib.dtype_code(dtype)) == (2 if dtype == torch.bfloat16 and H <= 64 else 4)
+    a, want, _ = _aggregate_case(dev, 400, 20000, H, Fe, seed=9, skew=True, dtype=dtype)
     ops.USE_MASKBITS = False
     try:
-        b, _, _ = _aggregate_case(dev, 400, 20000, 128, 4, seed=9, skew=True)
+        b, _, _ = _aggregate_case(dev, 400, 20000, H, Fe, seed=9, skew=True, dtype=dtype)
     finally:
         ops.USE_MASKBITS = True
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+    assert_close(a[0], want[0], RTOL32 if dtype == torch.float32 else RTOL16, what="sums")
 
 
 @pytest.mark.gpu
