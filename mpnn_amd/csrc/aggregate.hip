@@ -178,6 +178,8 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
 
   float w[VEC][FE];
   load_edge_weights<T, VEC, FE>(a.We, a.fe, c0, act, w);
+  const int ldb = (int)a.ldB;   // (checked on the host) row index times a 32-bit stride: one multiply-add per gather,
+                                // where the 64-bit stride takes three quarter-rate multiplies
 
   // TRAIN >= 3: the mask words of a finished chunk wait here (lane l: its own bytes of the chunk's edges) until the
   // next chunk's gathers are in flight; the exchange that turns them into per-edge records (three dependent trips
@@ -258,7 +260,7 @@ __global__ void __launch_bounds__(kBlock, fwd_waves(VEC, FE)) k_agg_fwd(FwdArgs<
         for (int u = 0; u < U; ++u) {
           const int jj = (j + u) < nb ? (j + u) : (nb - 1);
           const int s = __shfl(cur, jj, lpr);
-          braw[u] = RowIO<T, VEC>::load_raw(a.B + (int64_t)s * a.ldB + cc);
+          braw[u] = RowIO<T, VEC>::load_raw(a.B + (int64_t)s * ldb + cc);
         }
         if (OWN && j == 0) flush_mask();   // the previous chunk's words, while this chunk's rows arrive
 #pragma unroll
@@ -439,8 +441,8 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src(BwdArgs<T> a) {
         for (int u = 0; u < U; ++u) {
           const int jj = (j + u) < nb ? (j + u) : (nb - 1);
           const int d = __shfl(cur, jj, lpr);
-          RowIO<T, VEC>::load(a.A + (int64_t)d * a.ldA + cc, av[u]);
-          RowIO<T, VEC>::load(a.G + (int64_t)d * a.ldG + cc, gv[u]);
+          RowIO<T, VEC>::load(a.A + (int64_t)d * (int)a.ldA + cc, av[u]);   // (32-bit strides: checked on the host)
+          RowIO<T, VEC>::load(a.G + (int64_t)d * (int)a.ldG + cc, gv[u]);
           load_edge_attr<T, FE, RTFE>(a.ea, (int64_t)(base + jj), a.fe, ev[u]);
         }
 #pragma unroll
@@ -539,7 +541,7 @@ __global__ void __launch_bounds__(kBlock) k_agg_bwd_src_masked(BwdMaskArgs<T> a)
           const int jj = (j + u) < nb ? (j + u) : (nb - 1);
           const int d = __shfl(cur, jj, lpr);
           const int pp = __shfl(curp, jj, lpr);
-          RowIO<T, VEC>::load(a.G + (int64_t)d * a.ldG + cc, gv[u]);
+          RowIO<T, VEC>::load(a.G + (int64_t)d * (int)a.ldG + cc, gv[u]);   // (32-bit stride: checked on the host)
           if constexpr (FMT == 2) {
             // the word that holds this lane's byte (4 lanes per word: the group reads its 8 or 16 bytes as one piece)
             mw[u][0] = NT_LOAD(a.maskbits + (int64_t)pp * (lpr >> 2) + (lig >> 2));
@@ -934,6 +936,7 @@ int32_t mpnn_aggregate_fwd(const void* A, int64_t ldA, const void* B, int64_t ld
   if (num_nodes == 0 || n_items == 0) return MPNN_OK;
   if (!A || !B || !We || !items || !out) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: null pointer argument");
   if (ldA < H || ldB < H || ldo < H) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: leading dimension below H");
+  if (ldA > INT32_MAX || ldB > INT32_MAX) return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: leading dimension above 2^31 - 1");
   if (n_parts > 0 && (!part_out || (cnt && !part_cnt) || !split))
     return fail(MPNN_E_INVALID, "mpnn_aggregate_fwd: split rows present but scratch slabs are null");
   if (((uintptr_t)items & 15) || ((uintptr_t)split & 15))
@@ -1085,6 +1088,8 @@ int32_t mpnn_aggregate_bwd_src(const void* A, int64_t ldA, const void* B, int64_
     return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: null pointer argument");
   if (ldA < H || ldB < H || ldG < H || ldgB < H)
     return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: leading dimension below H");
+  if (ldA > INT32_MAX || ldG > INT32_MAX)
+    return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: leading dimension above 2^31 - 1");
   if (n_parts_t > 0 && (!part_gB || !split_t))
     return fail(MPNN_E_INVALID, "mpnn_aggregate_bwd_src: split rows present but scratch slab is null");
   if (((uintptr_t)items_t & 15) || ((uintptr_t)split_t & 15))
@@ -1126,6 +1131,7 @@ int32_t mpnn_aggregate_bwd_src_masked(const void* G, int64_t ldG, const uint32_t
   }
   if (!G || !maskbits || !tpos || !items_t || !gB) return fail(MPNN_E_INVALID, "%s: null pointer argument", who);
   if (ldG < H || ldgB < H) return fail(MPNN_E_INVALID, "%s: leading dimension below H", who);
+  if (ldG > INT32_MAX) return fail(MPNN_E_INVALID, "%s: leading dimension above 2^31 - 1", who);
   if (n_parts_t > 0 && (!part_gB || !split_t)) return fail(MPNN_E_INVALID, "%s: split rows present but scratch slab is null", who);
   const int full = dtype == MPNN_BF16 ? 8 : 4;
   if (!aligned16(G) || !aligned16(gB) || !aligned16(ea_sorted_t) || !aligned16(maskbits) || !aligned16(items_t) ||
