@@ -49,6 +49,12 @@ def test_argument_validation_reports_errors_without_a_gpu():
     rc = lib.mpnn_aggregate_fwd(None, 64, None, 64, None, 4, None, None, None, 1, None, 0, 0, None, 64, None, None,
                                 0, None, None, None, 1, 64, 0, None)
     assert rc == -1 and b"null" in lib.mpnn_last_error()
+    # row strides must fit 32 bits (the gather address is row * stride in one multiply-add); the pointers are never
+    # followed: the call is rejected first
+    fake = 1 << 20
+    rc = lib.mpnn_aggregate_fwd(fake, 1 << 31, fake, 64, fake, 4, fake, fake, fake, 1, None, 0, 0, fake, 64, None, None,
+                                0, None, None, None, 1, 64, 0, None)
+    assert rc == -1 and b"above 2^31" in lib.mpnn_last_error()
     rc = lib.mpnn_gather_rows(None, None, None, 4, 3, None)
     assert rc == -1
     rc = lib.mpnn_csr_build(None, None, -1, 4, 4, None, None, None, None, None, 0, None)
