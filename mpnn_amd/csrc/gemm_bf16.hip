@@ -371,10 +371,12 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
   };
   auto stash = [&](int buf, int64_t nslab) {
     const bool emit = a.gout && blockIdx.z == 0;   // uniform
-    const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+    // (zeroing by an all-ones / all-zeros word per piece: the compiler turns a select between two 16-byte values
+    // into a two-entry table in scratch memory, read back with a lane-indexed load for every piece)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      uint4 g = (rv[q] && g_ok) ? gr[q] : zero;
+      const uint32_t gk = (rv[q] && g_ok) ? ~0u : 0u, xk = (rv[q] && x_ok) ? ~0u : 0u;
+      uint4 g = make_uint4(gr[q].x & gk, gr[q].y & gk, gr[q].z & gk, gr[q].w & gk);
       if constexpr (MASKED) {
         g.x = relu_mask2(g.x, mr[q].x); g.y = relu_mask2(g.y, mr[q].y);
         g.z = relu_mask2(g.z, mr[q].z); g.w = relu_mask2(g.w, mr[q].w);
@@ -383,7 +385,8 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
       if (emit && rv[q] && g_ok)   // the masked gradient, one whole 256-byte row per 16 lanes
         *reinterpret_cast<uint4*>(a.gout + (nslab + r) * a.ldgo + gcol) = g;
       *reinterpret_cast<uint4*>(&Gs[buf][r * kTnRowB + pc * 2]) = g;
-      *reinterpret_cast<uint4*>(&Xs[buf][r * kTnRowB + pc * 2]) = (rv[q] && x_ok) ? xr[q] : zero;
+      *reinterpret_cast<uint4*>(&Xs[buf][r * kTnRowB + pc * 2]) =
+          make_uint4(xr[q].x & xk, xr[q].y & xk, xr[q].z & xk, xr[q].w & xk);
     }
   };
 
