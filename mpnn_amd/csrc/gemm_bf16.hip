@@ -310,11 +310,18 @@ struct TnBf16Args {
 };
 
 // Two packed bfloat16 of g where the matching entries of y are > 0 (NaN counts as > 0, like `y <= 0 ? 0 : g`).
+// Both halves at once on packed 16-bit integer instructions, and no compare: a compare's result can be used two
+// wait states later at the earliest, and this runs 8 times per thread and slab.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t relu_mask2(uint32_t g, uint32_t y) {
-  const uint32_t lo = y & 0xffffu, hi = y >> 16;
-  const bool keep_lo = (lo & 0x7fffu) != 0u && (!(lo & 0x8000u) || (lo & 0x7fffu) > 0x7f80u);
-  const bool keep_hi = (hi & 0x7fffu) != 0u && (!(hi & 0x8000u) || (hi & 0x7fffu) > 0x7f80u);
-  return g & ((keep_lo ? 0xffffu : 0u) | (keep_hi ? 0xffff0000u : 0u));
+  const u16x2 h = __builtin_bit_cast(u16x2, y);
+  // as a signed half word h > 0 (positive numbers, +inf, +NaN) <=> -h is negative and h is not (-0 = 0x8000 fails both)
+  const s16x2 pos = __builtin_bit_cast(s16x2, (u16x2)((u16x2)(0) - h) & ~h) >> 15;
+  // -NaN: above 0xff80 (-inf); the saturating difference is 1..0x7f there and 0 everywhere else
+  const u16x2 over = __builtin_elementwise_sub_sat(h, (u16x2)(0xff80));
+  const s16x2 nan = __builtin_bit_cast(s16x2, (u16x2)((u16x2)(0) - over)) >> 15;
+  return g & __builtin_bit_cast(uint32_t, pos | nan);
 }
 
 // 8 contraction values of one output column: rows +0..3 and +4..7 of the lane's 8.

@@ -889,3 +889,28 @@ def test_gemm_variants_agree(monkeypatch, dev):
     for form in ("single", "regs"):
         monkeypatch.setenv("MPNN_GEMM_TN", form)
         assert_close(gemm_tn(g, x, mask=mask, x2=x2), dw.double().cpu(), RTOL32, what=f"TN form {form}")
+
+
+@pytest.mark.gpu
+def test_bf16_weight_gradient_mask_on_special_values(dev):
+    """The relu mask inside the bfloat16 weight-gradient product keeps g exactly where torch's `y <= 0 ? 0 : g` does:
+    +0 / -0 / -inf / negative numbers drop, denormals, +inf and NaN of either sign keep (bit for bit, through the
+    masked gradient the kernel writes out)."""
+    from mpnn_amd.dense import gemm_tn_bf16
+    gen = torch.Generator().manual_seed(5)
+    g = torch.randn(4096, 128, generator=gen).to(dev).bfloat16()
+    x = torch.randn(4096, 128, generator=gen).to(dev).bfloat16()
+    y = torch.randn(4096, 128, generator=gen).to(dev).bfloat16()
+    special = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1e-38, -1e-38, 3.0, -3.0]).to(dev).bfloat16()
+    neg_nan = torch.tensor([-1], dtype=torch.int16, device=dev).view(torch.bfloat16)      # 0xffff: NaN with the sign bit
+    flat = y.view(-1)
+    flat[:9] = special
+    flat[9] = neg_nan[0]
+    flat[4096:4105] = special          # the other half of a packed pair, another row
+    flat[4105] = neg_nan[0]
+    gz = torch.empty_like(g)
+    out = torch.empty(128, 128, device=dev, dtype=torch.bfloat16)
+    gemm_tn_bf16(g, x, mask=y, out=out, g_out=gz)
+    want = torch.where(y <= 0, torch.zeros_like(g), g)
+    assert torch.equal(gz.view(torch.int16), want.view(torch.int16))
+    assert_close(out, want.double().cpu().t() @ x.double().cpu(), RTOL16, what="masked weight gradient")
