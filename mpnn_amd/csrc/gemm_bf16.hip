@@ -160,11 +160,14 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt_bf16(NtBf16Args a) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[t], 0, 0, 0);
       }
     }
-    if (last_chunk && a.Y2) {
-      // Three arrays are touched (Y, emul, Y2): the tiles go through a wave-private patch of the LDS buffer that
+    if (last_chunk && (a.Y2 || MT == 4)) {
+      // The tiles go through a wave-private patch of the LDS buffer that
       // has just been multiplied (free once every wave has left the loop above; its next writer is the stash of
       // the following iteration, behind this iteration's closing barrier) and leave as whole row segments,
-      // 8 columns per lane.  TPB tiles share a patch when the buffer is large enough.
+      // 8 columns per lane.  TPB tiles share a patch when the buffer is large enough.  With the second output
+      // (Y2 = Y * emul) three arrays are touched here; for a single output of 4 tiles per wave it is still the
+      // faster way out - the registers hold a tile transposed, 8 bytes per lane in 32 different rows per store,
+      // and the 2 GB of a 256-column product written that way took half as long again (1.00 vs 0.66 ms).
       __syncthreads();
       constexpr int TPB = (MT == 4 && WC == 1) ? 2 : 1;
       constexpr int PITCH = 32 * TPB + 4;                 // floats; 16-byte slots per row odd
@@ -199,6 +202,7 @@ __global__ void __launch_bounds__(kBlock * WC, 2) k_gemm_nt_bf16(NtBf16Args a) {
           if (row < a.N && col < a.M) {   // M is a multiple of 8: a lane's 8 columns are inside or outside
             *reinterpret_cast<uint4*>(a.Y + row * a.ldy + col) =
                 make_uint4(pack2_bf16(v0.x, v0.y), pack2_bf16(v0.z, v0.w), pack2_bf16(v1.x, v1.y), pack2_bf16(v1.z, v1.w));
+            if (!a.Y2) continue;   // uniform over the launch
             float4 e0, e1;
             if (a.emul8) {   // uniform over the launch
               const uint2 w = *reinterpret_cast<const uint2*>(a.emul8 + row * a.ldemul + col);
