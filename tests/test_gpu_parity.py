@@ -914,3 +914,46 @@ def test_bf16_weight_gradient_mask_on_special_values(dev):
     want = torch.where(y <= 0, torch.zeros_like(g), g)
     assert torch.equal(gz.view(torch.int16), want.view(torch.int16))
     assert_close(out, want.double().cpu().t() @ x.double().cpu(), RTOL16, what="masked weight gradient")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H", [64, 128])
+def test_bf16_mask_bytes_at_the_chunk_boundaries(H, dev):
+    """Rows with 0, 1, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 64 and 65 in-edges: the lane-owned mask bytes of the
+    bfloat16 forward are collected per word of 4 edges and per chunk of 8 (H = 64) or 16 (H = 128) edges, and a
+    finished chunk's bytes are written while the next one is under way - every boundary of that scheme once.  Sums
+    against the float64 oracle, and the backward that reads the bytes against the one that recomputes, bit for bit."""
+    from mpnn_amd import ops
+    from mpnn_amd.graph import MPGraph
+    from mpnn_amd.ops import aggregate_fused
+    degrees = [0, 1, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 64, 65] * 3
+    n, fe = len(degrees), 4
+    gen = torch.Generator().manual_seed(H)
+    dst = torch.repeat_interleave(torch.arange(n), torch.tensor(degrees))
+    e = dst.numel()
+    dst = dst[torch.randperm(e, generator=gen)]
+    src = torch.randint(0, n, (e,), generator=gen)
+    ei = torch.stack([src, dst])
+    ab = torch.randn(n, 2 * H, generator=gen).bfloat16().float()
+    ea = torch.rand(e, fe, generator=gen).bfloat16().float()
+    we = (torch.randn(H, fe, generator=gen) * 0.5).bfloat16().float()
+    r = torch.randn(n, H, generator=gen)
+    want = O.aggregate_sum_form(ab[:, :H], ab[:, H:], ea, we, ei)
+
+    def run():
+        graph = MPGraph(ei.to(dev), n)
+        ab_g = ab.to(dev, torch.bfloat16).requires_grad_(True)
+        we_g = we.to(dev, torch.bfloat16).requires_grad_(True)
+        got = aggregate_fused(ab_g, ea.to(dev, torch.bfloat16), we_g, graph)
+        (got.float() * r.to(dev)).sum().backward()
+        return got, ab_g.grad, we_g.grad
+
+    with_bytes = run()
+    ops.USE_MASKBITS = False
+    try:
+        recomputed = run()
+    finally:
+        ops.USE_MASKBITS = True
+    for a, b in zip(with_bytes, recomputed):
+        assert torch.equal(a, b)
+    assert_close(with_bytes[0], want, RTOL16, what="sums")
