@@ -335,25 +335,40 @@ __device__ __forceinline__ bf16x8 read_col8(const char* p) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-// Output tile 128 (m) x 128 (k) per block; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles); blockIdx.x
-// walks the row slabs with stride gridDim.x and leaves one partial tile.
-template <bool MASKED>
-__global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
+// Output tile 128 (m) x 128 (k) per 4 waves; wave (wm, wk) owns a 64 x 64 quadrant (2 x 2 MFMA tiles); blockIdx.x
+// walks the row slabs with stride gridDim.x and leaves one partial tile.  PAIR: a block of 8 waves owns TWO column
+// tiles of [X | X2] (waves 0-3 the first, 4-7 the second) against one slab of G in LDS: G and its mask are read once
+// for both, where separate blocks read them once each (their slabs drift apart, and the L2 catches only part).
+template <bool MASKED, bool PAIR>
+__global__ void __launch_bounds__(PAIR ? 2 * kBlock : kBlock) k_gemm_tn_bf16(TnBf16Args a) {
+  constexpr int NX = PAIR ? 2 : 1;   // column tiles per block
+  constexpr int Q = PAIR ? 1 : 2;    // 16-byte pieces per thread, matrix and slab
   __shared__ __attribute__((aligned(16))) char Gs[2][kTnRows * kTnRowB];
-  __shared__ __attribute__((aligned(16))) char Xs[2][kTnRows * kTnRowB];
+  __shared__ __attribute__((aligned(16))) char Xs[2][NX][kTnRows * kTnRowB];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = (wid >> 1) * 64, wk = (wid & 1) * 64;
-  // the right-hand matrix this block's column tile lies in, the tile's first column there and in dW
-  const int z1 = (a.K + 127) / 128;
-  const bool second = a.X2 && (int)blockIdx.z >= z1;
-  const bf16_t* const xm = second ? a.X2 : a.X;
-  const int64_t ldxm = second ? a.ldx2 : a.ldx;
-  const int km = second ? a.K2 : a.K;
-  const int m0 = blockIdx.y * 128, k0 = (second ? (int)blockIdx.z - z1 : (int)blockIdx.z) * 128;
-  const int kout0 = second ? a.K + k0 : k0;
+  const int tw = PAIR ? wid >> 2 : 0;   // the column tile this wave multiplies
+  const int wm = ((wid >> 1) & 1) * 64, wk = (wid & 1) * 64;
+  // per column tile: the right-hand matrix it lies in, its first column there and in dW
+  const int z1 = (a.K + 127) / 128, z2 = a.X2 ? (a.K2 + 127) / 128 : 0;
+  const bf16_t* xm[NX];
+  int64_t ldxm[NX];
+  int km[NX], k0[NX], kout0[NX];
+  bool tile_ok[NX];
+#pragma unroll
+  for (int t = 0; t < NX; ++t) {
+    const int zt = NX * (int)blockIdx.z + t;
+    tile_ok[t] = zt < z1 + z2;
+    const bool second = tile_ok[t] && zt >= z1;
+    xm[t] = second ? a.X2 : a.X;
+    ldxm[t] = second ? a.ldx2 : a.ldx;
+    km[t] = second ? a.K2 : a.K;
+    k0[t] = tile_ok[t] ? (second ? zt - z1 : zt) * 128 : 0;
+    kout0[t] = second ? a.K + k0[t] : k0[t];
+  }
+  const int m0 = blockIdx.y * 128;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -363,30 +378,38 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // a thread moves two 16-byte pieces per matrix and slab: rows tid/16 and tid/16 + 16, columns 8 (tid % 16) ..
+  // a thread moves Q 16-byte pieces per matrix and slab: rows tid / 16 (+ 16), columns 8 (tid % 16) ..
   const int pr = tid >> 4, pc = (tid & 15) * 8;
-  const bool g_ok = m0 + pc < a.M, x_ok = k0 + pc < km;   // widths are multiples of 8: a piece is in or out
-  const int gcol = g_ok ? m0 + pc : 0, xcol = x_ok ? k0 + pc : 0;
-  uint4 gr[2], mr[2], xr[2];
-  bool rv[2];
-  auto fetch = [&](int64_t n0) {
+  const bool g_ok = m0 + pc < a.M;   // widths are multiples of 8: a piece is in or out
+  const int gcol = g_ok ? m0 + pc : 0;
+  bool x_ok[NX];
+  int xcol[NX];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+  for (int t = 0; t < NX; ++t) {
+    x_ok[t] = tile_ok[t] && k0[t] + pc < km[t];
+    xcol[t] = x_ok[t] ? k0[t] + pc : 0;
+  }
+  uint4 gr[Q], mr[Q], xr[Q][NX];
+  bool rv[Q];
+  auto fetch = [&](int64_t n0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
       int64_t row = n0 + pr + 16 * q;
       rv[q] = row < a.N;   // rows past the end must contribute exact zeros to the sums
       row = rv[q] ? row : a.N - 1;
       gr[q] = *reinterpret_cast<const uint4*>(a.G + row * a.ldg + gcol);
       if constexpr (MASKED) mr[q] = *reinterpret_cast<const uint4*>(a.mask + row * a.ldm + gcol);
-      xr[q] = *reinterpret_cast<const uint4*>(xm + row * ldxm + xcol);
+#pragma unroll
+      for (int t = 0; t < NX; ++t) xr[q][t] = *reinterpret_cast<const uint4*>(xm[t] + row * ldxm[t] + xcol[t]);
     }
   };
-  auto stash = [&](int buf, int64_t nslab) {
+  auto stash = [&](int buf, int64_t nslab) __attribute__((always_inline)) {
     const bool emit = a.gout && blockIdx.z == 0;   // uniform
     // (zeroing by an all-ones / all-zeros word per piece: the compiler turns a select between two 16-byte values
     // into a two-entry table in scratch memory, read back with a lane-indexed load for every piece)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const uint32_t gk = (rv[q] && g_ok) ? ~0u : 0u, xk = (rv[q] && x_ok) ? ~0u : 0u;
+    for (int q = 0; q < Q; ++q) {
+      const uint32_t gk = (rv[q] && g_ok) ? ~0u : 0u;
       uint4 g = make_uint4(gr[q].x & gk, gr[q].y & gk, gr[q].z & gk, gr[q].w & gk);
       if constexpr (MASKED) {
         g.x = relu_mask2(g.x, mr[q].x); g.y = relu_mask2(g.y, mr[q].y);
@@ -396,8 +419,12 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
       if (emit && rv[q] && g_ok)   // the masked gradient, one whole 256-byte row per 16 lanes
         *reinterpret_cast<uint4*>(a.gout + (nslab + r) * a.ldgo + gcol) = g;
       *reinterpret_cast<uint4*>(&Gs[buf][r * kTnRowB + pc * 2]) = g;
-      *reinterpret_cast<uint4*>(&Xs[buf][r * kTnRowB + pc * 2]) =
-          make_uint4(xr[q].x & xk, xr[q].y & xk, xr[q].z & xk, xr[q].w & xk);
+#pragma unroll
+      for (int t = 0; t < NX; ++t) {
+        const uint32_t xk = (rv[q] && x_ok[t]) ? ~0u : 0u;
+        *reinterpret_cast<uint4*>(&Xs[buf][t][r * kTnRowB + pc * 2]) =
+            make_uint4(xr[q][t].x & xk, xr[q][t].y & xk, xr[q][t].z & xk, xr[q][t].w & xk);
+      }
     }
   };
 
@@ -416,7 +443,7 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
     const bool more = n0 + step < a.N;
     if (more) fetch(n0 + step);
     const char* gp = &Gs[buf][frag_off + wm * 2];
-    const char* xp = &Xs[buf][frag_off + wk * 2];
+    const char* xp = &Xs[buf][tw][frag_off + wk * 2];
 #pragma unroll
     for (int s = 0; s < kTnRows / 16; ++s) {
       const bf16x8 a0 = read_col8(gp + s * 16 * kTnRowB), a1 = read_col8(gp + s * 16 * kTnRowB + 64);
@@ -429,17 +456,22 @@ __global__ void __launch_bounds__(kBlock) k_gemm_tn_bf16(TnBf16Args a) {
     if (more) stash(buf ^ 1, n0 + step);
     __syncthreads();
   }
+  // this wave's column tile (scalars picked by a select: an indexed local array would live in scratch memory)
+  const bool my_ok = PAIR && tw ? tile_ok[NX - 1] : tile_ok[0];
+  const int my_k0 = PAIR && tw ? k0[NX - 1] : k0[0], my_km = PAIR && tw ? km[NX - 1] : km[0];
+  const int my_kout0 = PAIR && tw ? kout0[NX - 1] : kout0[0];
+  if (!my_ok) return;
   const int ktot = a.K + a.K2;
   float* out = a.partial + (int64_t)blockIdx.x * a.M * ktot;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int cl = k0 + wk + j * 32 + li;   // column inside the tile's matrix
+      const int cl = my_k0 + wk + j * 32 + li;   // column inside the tile's matrix
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < a.M && cl < km) out[(int64_t)row * ktot + (kout0 - k0) + cl] = acc[i][j][r];
+        if (row < a.M && cl < my_km) out[(int64_t)row * ktot + (my_kout0 - my_k0) + cl] = acc[i][j][r];
       }
     }
 }
@@ -549,9 +581,15 @@ extern "C" int32_t mpnn_gemm_tn_bf16(const void* G, int64_t ldg, const void* mas
                static_cast<const bf16_t*>(X2), ldx2, static_cast<bf16_t*>(Gout), ldgo, scratch, N, M, K, K2};
   const int ztiles = (K + 127) / 128 + (K2 + 127) / 128;
   const int slabs = tn_bf16_slabs(N, M, ztiles * 128);
-  dim3 grid(slabs, (M + 127) / 128, ztiles);
-  if (mask) k_gemm_tn_bf16<true><<<grid, kBlock, 0, stream>>>(a);
-  else k_gemm_tn_bf16<false><<<grid, kBlock, 0, stream>>>(a);
+  if (ztiles >= 2) {   // blocks of 8 waves that own two column tiles each and read G (and its mask) once for both
+    dim3 grid(slabs, (M + 127) / 128, (ztiles + 1) / 2);
+    if (mask) k_gemm_tn_bf16<true, true><<<grid, 2 * kBlock, 0, stream>>>(a);
+    else k_gemm_tn_bf16<false, true><<<grid, 2 * kBlock, 0, stream>>>(a);
+  } else {
+    dim3 grid(slabs, (M + 127) / 128, ztiles);
+    if (mask) k_gemm_tn_bf16<true, false><<<grid, kBlock, 0, stream>>>(a);
+    else k_gemm_tn_bf16<false, false><<<grid, kBlock, 0, stream>>>(a);
+  }
   MPNN_LAUNCH_CHECK("k_gemm_tn_bf16");
   int64_t blocks = ((int64_t)M * ktot + 63) / 64;
   if (blocks > kMaxBlocks) blocks = kMaxBlocks;
